@@ -1,0 +1,169 @@
+/*
+ * ldpc_hip.h -- C ABI of libldpc_hip.so: LDPC code evaluation on AMD MI355X (gfx950).
+ *
+ * This is the drop-in boundary for the one data-parallel hot path of
+ * Omer-Sella/ldpc: channel -> iterative decode -> syndrome early stop ->
+ * error counting.  Every entry point names the reference interface it replaces
+ * (paths relative to the reference checkout).  Plain C, ctypes/cffi loadable,
+ * no C++ or torch types.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative LDPC_E_* code; the text
+ *     of the last error of the calling thread is in ldpc_last_error();
+ *   - the caller owns every buffer it passes; the library owns only what hangs
+ *     off an ldpc_handle;
+ *   - one handle = one device + one stream + one code; a handle must not be
+ *     used from two threads at once, distinct handles may be;
+ *   - there is NO CPU fallback: without a usable HIP device every compute entry
+ *     point fails with LDPC_E_DEVICE.
+ *
+ * Decoder contract (identical to the reference's, bit for bit, see
+ * ldpc.py:326-337): channel values y (positive = bit 1, ldpc.py:43-48,62-66);
+ * if H*(y>0) == 0 return after 0 iterations; otherwise at most max_iters
+ * flooding iterations of plain min-sum (no scaling/offset, ldpc.py:174-202),
+ * variable update = sum of check messages in ascending check index with the
+ * channel value added last (ldpc.py:298-303, 322), stop as soon as the
+ * syndrome of the posterior hard decision is zero (ldpc.py:332-335).
+ */
+#ifndef LDPC_HIP_H
+#define LDPC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ldpc_handle ldpc_handle;
+
+enum {
+    LDPC_OK = 0,
+    LDPC_E_ARG = -1,      /* bad argument (NULL, size, range)                    */
+    LDPC_E_DEVICE = -2,   /* no HIP device / HIP runtime error                   */
+    LDPC_E_UNSUPPORTED = -3, /* code or option outside what the kernels cover    */
+    LDPC_E_NOMEM = -4
+};
+
+enum { LDPC_ALGO_MINSUM = 0, LDPC_ALGO_SUMPRODUCT = 1 };
+enum { LDPC_SIGN_REFERENCE = 0, LDPC_SIGN_CORRECTED = 1 };
+
+/* Text of the last error raised on the calling thread ("" if none). */
+const char *ldpc_last_error(void);
+
+/* Number of visible HIP devices (0 if none / runtime unusable).
+ * Replaces numba.cuda.gpus / cuda.select_device, ldpcCUDA.py:42-45. */
+int ldpc_device_count(void);
+
+/*
+ * Build a decoder for a quasi-cyclic parity-check matrix made of mb x nb
+ * circulant blocks of size Z.  Block (b, j), 0 <= b < mb, 0 <= j < nb, is a sum
+ * of cyclic shifts: row i of the block has ones at columns (i + s) mod Z for
+ * every s in shifts[blk_ptr[b*nb+j] .. blk_ptr[b*nb+j+1]) (distinct, any order,
+ * possibly none).  This is the matrix fileHandler.readMatrixFromFile(...,
+ * isGenerator=False) builds from a hot-position file (fileHandler.py:137-142,
+ * 161-181) and wifiMatrices.getWifiParityMatrix builds from its shift table
+ * (wifiMatrices.py:12-34).
+ * Replaces ldpcDecoder.__init__ (ldpc.py:225-247) and the dense device upload
+ * of ldpcCUDA.py:538-564.  Limits: check degree <= 64, mb*roundup(Z,64) <= 1024.
+ */
+int ldpc_create_qc(int device, int Z, int mb, int nb, const int32_t *blk_ptr,
+                   const int32_t *shifts, ldpc_handle **out);
+
+/*
+ * Build a decoder for an arbitrary sparse H given as CSR (row_ptr[m+1],
+ * col_idx ascending inside a row).  Replaces ldpcDecoder.__init__
+ * (ldpc.py:225-247) for matrices that are not block-circulant.
+ * Limits: check degree <= 64.
+ */
+int ldpc_create_csr(int device, int m, int n, const int32_t *row_ptr,
+                    const int32_t *col_idx, ldpc_handle **out);
+
+void ldpc_destroy(ldpc_handle *h);
+
+/* Code dimensions of a handle. */
+int ldpc_get_dims(const ldpc_handle *h, int *m, int *n, int *edges);
+
+/* Make the handle launch on an existing HIP stream (hipStream_t passed as
+ * void*; NULL = the handle's own stream).  No counterpart in the reference
+ * (numba's default stream, ldpcCUDA.py:594-662). */
+int ldpc_set_stream(ldpc_handle *h, void *hip_stream);
+
+/* Block until everything queued on the handle's stream has finished. */
+int ldpc_sync(ldpc_handle *h);
+
+/*
+ * Decode n_frames frames held in HOST memory.
+ *   llr        [n_frames][n] channel values (row-major), float32 (llr_bits 32:
+ *              what ldpcCUDA.addAWGN produces, ldpcCUDA.py:514) or float64
+ *              (llr_bits 64: what ldpc.addAWGN produces, ldpc.py:57-59)
+ *   hard_bits  [n_frames][ceil(n/8)] or NULL; bit c of a frame is
+ *              (byte c>>3) >> (c&7) & 1  (numpy.packbits bitorder='little')
+ *   iters      [n_frames] completed iterations (0 if y is already a codeword)
+ *   converged  [n_frames] 1 = 'Codeword', 0 = 'Not a codeword'
+ *   ones       [n_frames] or NULL: number of 1 bits in the hard decision
+ *              (= bit errors against the all-zero codeword, ldpc.py:381)
+ *   soft_out   [n_frames][n] float32 (prec 32) or float64 (prec 64), or NULL:
+ *              the posterior vector decoderMainLoop returns (ldpc.py:337)
+ * prec: 32 = float32 arithmetic (the reference's GPU path, ldpcCUDA.py:538-548),
+ *       64 = float64 arithmetic (the reference's CPU path, ldpc.py:29).
+ * Synchronous.  Replaces ldpcDecoder.decoderMainLoop (ldpc.py:326-337) and the
+ * per-frame body of ldpcCUDA.evaluateCodeCuda (ldpcCUDA.py:583-662).
+ */
+int ldpc_decode(ldpc_handle *h, int algo, int prec, int sign_mode, int max_iters,
+                int64_t n_frames, const void *llr, int llr_bits, uint8_t *hard_bits,
+                int32_t *iters, uint8_t *converged, int32_t *ones, void *soft_out);
+
+/*
+ * Same, with every buffer in DEVICE memory of the handle's device; queued on
+ * the handle's stream, returns without waiting.  llr_scale multiplies the
+ * channel values on load (1.0 for min-sum parity with the reference, whose
+ * "LLR" is the raw channel value; 2/sigma^2 for sum-product).
+ */
+int ldpc_decode_device(ldpc_handle *h, int algo, int prec, int sign_mode, int max_iters,
+                       int64_t n_frames, const void *d_llr, int llr_bits, float llr_scale,
+                       uint8_t *d_hard_bits, int32_t *d_iters, uint8_t *d_converged,
+                       int32_t *d_ones, void *d_soft_out);
+
+/*
+ * Fill d_llr [n_frames][n] (device) with BPSK/AWGN channel outputs of the
+ * all-zero codeword: y = -1 + sigma*N(0,1), sigma = sqrt(0.5 / 10^(snr_db/10))
+ * (ldpc.py:51-66; no code-rate term).  Noise is counter based: sample (frame
+ * first_frame+f, position c) depends only on (seed, first_frame+f, c), so any
+ * sharding over devices sees the same frames.  Optional per-frame outputs:
+ *   d_sigma_hat [n_frames] float: sqrt(sum(noise^2)/n)  (sigmaActual, ldpc.py:58)
+ *   d_uncoded   [n_frames] int32: channel hard-decision errors (ldpcCUDA.py:586-587)
+ * Queued on the handle's stream.  Replaces addAWGN/modulate/slicer on the
+ * host (ldpcCUDA.py:497-517, 581-587).
+ */
+int ldpc_channel_awgn_device(ldpc_handle *h, double snr_db, uint64_t seed, uint64_t first_frame,
+                             int64_t n_frames, float *d_llr, float *d_sigma_hat,
+                             int32_t *d_uncoded);
+
+/*
+ * Monte-Carlo evaluation: for every SNR point generate frames_per_snr frames
+ * on the device (ldpc_channel_awgn_device, frame ids first_frame ..
+ * first_frame+frames_per_snr-1, stream id = index of the SNR point), decode
+ * them and count.  Host outputs:
+ *   counters  [n_snr][6] uint64: frames, frame errors (hard decision != 0),
+ *             decoded bit errors, sum of iterations, uncoded bit errors,
+ *             frames with status 'Not a codeword'
+ *   per_frame [n_snr][frames_per_snr][4] float or NULL: sigma_hat, uncoded
+ *             errors, decoded errors, iterations  (the columns of a
+ *             berStatistics row, common.py:149-157)
+ * Synchronous.  Replaces the SNR x transmissions loops of ldpc.evaluateCode
+ * (ldpc.py:350-388) and ldpcCUDA.evaluateCodeCuda (ldpcCUDA.py:576-664).
+ */
+int ldpc_eval_awgn(ldpc_handle *h, int algo, int prec, int sign_mode, int max_iters,
+                   int n_snr, const double *snr_db, int64_t frames_per_snr,
+                   uint64_t seed, uint64_t first_frame, uint64_t *counters,
+                   float *per_frame);
+
+/* Launch geometry the decoder uses for (algo, prec): workgroups, threads per
+ * workgroup, dynamic LDS bytes, frames per workgroup.  For reports. */
+int ldpc_get_launch_info(ldpc_handle *h, int algo, int prec, int *grid, int *block,
+                         int *lds_bytes, int *frames_per_wg);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LDPC_HIP_H */

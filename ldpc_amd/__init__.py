@@ -1,0 +1,13 @@
+"""ldpc_amd -- LDPC code evaluation on AMD MI355X (gfx950).
+
+Host-side mirror of the Python entry points of Omer-Sella/ldpc's decode path
+(``ldpc.py``, the GPU driver of ``ldpcCUDA.py``, ``common.berStatistics``,
+``fileHandler.readMatrixFromFile``, ``wifiMatrices.getWifiParityMatrix``) on
+top of ``libldpc_hip.so`` (hand-written HIP kernels behind a C ABI, see
+include/ldpc_hip.h).  There is no CPU fallback: decoding without the built
+library or without a HIP device raises.
+"""
+from . import codes, common  # noqa: F401
+from .engine import Decoder, LdpcHipError, device_count, library_path  # noqa: F401
+
+__all__ = ['codes', 'common', 'Decoder', 'LdpcHipError', 'device_count', 'library_path']

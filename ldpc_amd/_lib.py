@@ -1,0 +1,63 @@
+"""ctypes binding of libldpc_hip.so (C ABI declared in include/ldpc_hip.h)."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_NAME = 'libldpc_hip.so'
+
+# every symbol include/ldpc_hip.h declares
+SYMBOLS = (
+    'ldpc_last_error', 'ldpc_device_count', 'ldpc_create_qc', 'ldpc_create_csr', 'ldpc_destroy',
+    'ldpc_get_dims', 'ldpc_set_stream', 'ldpc_sync', 'ldpc_decode', 'ldpc_decode_device',
+    'ldpc_channel_awgn_device', 'ldpc_eval_awgn', 'ldpc_get_launch_info',
+)
+
+_lib = None
+
+
+def library_path():
+    return os.environ.get('LDPC_HIP_LIBRARY', os.path.join(_HERE, LIB_NAME))
+
+
+def load():
+    """Load the HIP library or raise; never falls back to anything else."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise ImportError(
+            f'{path} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+            f'or `make -C ldpc_amd/csrc` (hipcc --offload-arch=gfx950). There is no CPU fallback.')
+    L = ctypes.CDLL(path)
+    c = ctypes
+    vp, i32, i64, u64, dbl, flt = c.c_void_p, c.c_int, c.c_int64, c.c_uint64, c.c_double, c.c_float
+    L.ldpc_last_error.restype = c.c_char_p
+    L.ldpc_last_error.argtypes = []
+    L.ldpc_device_count.restype = i32
+    L.ldpc_device_count.argtypes = []
+    L.ldpc_create_qc.restype = i32
+    L.ldpc_create_qc.argtypes = [i32, i32, i32, i32, vp, vp, c.POINTER(vp)]
+    L.ldpc_create_csr.restype = i32
+    L.ldpc_create_csr.argtypes = [i32, i32, i32, vp, vp, c.POINTER(vp)]
+    L.ldpc_destroy.restype = None
+    L.ldpc_destroy.argtypes = [vp]
+    L.ldpc_get_dims.restype = i32
+    L.ldpc_get_dims.argtypes = [vp, c.POINTER(i32), c.POINTER(i32), c.POINTER(i32)]
+    L.ldpc_set_stream.restype = i32
+    L.ldpc_set_stream.argtypes = [vp, vp]
+    L.ldpc_sync.restype = i32
+    L.ldpc_sync.argtypes = [vp]
+    L.ldpc_decode.restype = i32
+    L.ldpc_decode.argtypes = [vp, i32, i32, i32, i32, i64, vp, i32, vp, vp, vp, vp, vp]
+    L.ldpc_decode_device.restype = i32
+    L.ldpc_decode_device.argtypes = [vp, i32, i32, i32, i32, i64, vp, i32, flt, vp, vp, vp, vp, vp]
+    L.ldpc_channel_awgn_device.restype = i32
+    L.ldpc_channel_awgn_device.argtypes = [vp, dbl, u64, u64, i64, vp, vp, vp]
+    L.ldpc_eval_awgn.restype = i32
+    L.ldpc_eval_awgn.argtypes = [vp, i32, i32, i32, i32, i32, vp, i64, u64, u64, vp, vp]
+    L.ldpc_get_launch_info.restype = i32
+    L.ldpc_get_launch_info.argtypes = [vp, i32, i32, c.POINTER(i32), c.POINTER(i32), c.POINTER(i32),
+                                       c.POINTER(i32)]
+    _lib = L
+    return L

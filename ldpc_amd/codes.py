@@ -1,0 +1,185 @@
+"""Parity-check matrices of the codes the evaluation path is used with, and the
+conversions between their three representations:
+
+  dense H (what every reference entry point takes, int array m x n)
+  QC shift lists (Z, mb, nb, per-block list of shifts) -- what the HIP kernels use
+  CSR (row_ptr, col_idx) -- fallback for matrices that are not block-circulant
+
+Circulant convention (fileHandler.py:137-142, wifiMatrices.py:21-25): a block
+with hot position s has a one at (row i, column (i + s) mod Z).
+"""
+import numpy as np
+
+# CCSDS 131.1-O-2 "Near-Earth" (8176,7156) code: hot positions of the first row
+# of each 511x511 circulant, 2 block-rows x 16 block-columns.  Same numbers as
+# the reference's data file codeMatrices/nearEarthParity.txt (line 16*b+j+1).
+NEAR_EARTH_Z = 511
+NEAR_EARTH_HOT = (
+    ((0, 176), (12, 239), (0, 352), (24, 431), (0, 392), (151, 409), (0, 351), (9, 359),
+     (0, 307), (53, 329), (0, 207), (18, 281), (0, 399), (202, 457), (0, 247), (36, 261)),
+    ((99, 471), (130, 473), (198, 435), (260, 478), (215, 420), (282, 481), (48, 396), (193, 445),
+     (273, 430), (302, 451), (96, 379), (191, 386), (244, 467), (364, 470), (51, 382), (192, 414)),
+)
+
+# IEEE 802.11n, n = 1944, Z = 81, rate 5/6 prototype matrix (-1 = empty block).
+# The only WiFi matrix the reference carries (wifiMatrices.py:6-9).
+WIFI_1944_Z = 81
+WIFI_1944_R56 = (
+    (13, 48, 80, 66, 4, 74, 7, 30, 76, 52, 37, 60, -1, 49, 73, 31, 74, 73, 23, -1, 1, 0, -1, -1),
+    (69, 63, 74, 56, 64, 77, 57, 65, 6, 16, 51, -1, 64, -1, 68, 9, 48, 62, 54, 27, -1, 0, 0, -1),
+    (51, 15, 0, 80, 24, 25, 42, 54, 44, 71, 71, 9, 67, 35, -1, 58, -1, 29, -1, 53, 0, -1, 0, 0),
+    (16, 29, 36, 41, 44, 56, 59, 37, 50, 24, -1, 65, 4, 65, 52, -1, 4, -1, 73, 52, 1, -1, -1, 0),
+)
+
+
+class QCCode:
+    """Quasi-cyclic code as per-block shift lists.
+
+    blocks[b][j] is a tuple of distinct shifts (possibly empty); row i of block
+    (b, j) has ones at columns (i + s) mod Z.
+    """
+
+    def __init__(self, Z, blocks):
+        self.Z = int(Z)
+        self.blocks = tuple(tuple(tuple(int(s) for s in blk) for blk in row) for row in blocks)
+        self.mb = len(self.blocks)
+        self.nb = len(self.blocks[0])
+        for row in self.blocks:
+            if len(row) != self.nb:
+                raise ValueError('ragged block table')
+            for blk in row:
+                if len(set(blk)) != len(blk) or any(s < 0 or s >= self.Z for s in blk):
+                    raise ValueError('shifts of a block must be distinct and in [0, Z)')
+        self.m = self.mb * self.Z
+        self.n = self.nb * self.Z
+
+    @property
+    def nnz(self):
+        return self.Z * sum(len(blk) for row in self.blocks for blk in row)
+
+    def row_degrees(self):
+        return [sum(len(blk) for blk in row) for row in self.blocks]
+
+    def col_degrees(self):
+        return [sum(len(self.blocks[b][j]) for b in range(self.mb)) for j in range(self.nb)]
+
+    def flat(self):
+        """(blk_ptr int32[mb*nb+1], shifts int32[...]) as ldpc_create_qc takes them."""
+        ptr = [0]
+        sh = []
+        for row in self.blocks:
+            for blk in row:
+                sh.extend(blk)
+                ptr.append(len(sh))
+        return np.asarray(ptr, np.int32), np.asarray(sh, np.int32)
+
+    def to_dense(self, dtype=np.int32):
+        Z = self.Z
+        H = np.zeros((self.m, self.n), dtype=dtype)
+        i = np.arange(Z)
+        for b, row in enumerate(self.blocks):
+            for j, blk in enumerate(row):
+                for s in blk:
+                    H[b * Z + i, j * Z + (i + s) % Z] = 1
+        return H
+
+    def with_block(self, b, j, shifts):
+        """Copy with block (b, j) replaced -- the gym's replaceCirculant (ldpc_env.py:293-317)."""
+        blocks = [list(row) for row in self.blocks]
+        blocks[b][j] = tuple(shifts)
+        return QCCode(self.Z, blocks)
+
+    def key(self):
+        return ('qc', self.Z, self.blocks)
+
+
+def near_earth():
+    return QCCode(NEAR_EARTH_Z, NEAR_EARTH_HOT)
+
+
+def near_earth_zeroed(b, j):
+    """NearEarth with circulant (b, j) zeroed (testMatricesGeneratorScript.py:27-31)."""
+    return near_earth().with_block(b, j, ())
+
+
+def wifi_1944_r56():
+    return QCCode(WIFI_1944_Z, [[() if s < 0 else (s,) for s in row] for row in WIFI_1944_R56])
+
+
+def dense_to_qc(H, Z):
+    """QCCode of a dense H if every Z x Z block is a sum of cyclic shifts, else None."""
+    H = np.asarray(H)
+    m, n = H.shape
+    if Z <= 0 or m % Z or n % Z:
+        return None
+    mb, nb = m // Z, n // Z
+    i = np.arange(Z)
+    blocks = []
+    for b in range(mb):
+        row = []
+        for j in range(nb):
+            blk = H[b * Z:(b + 1) * Z, j * Z:(j + 1) * Z]
+            hot = np.flatnonzero(blk[0])
+            if np.count_nonzero(blk) != Z * len(hot):
+                return None
+            for s in hot:
+                if not np.all(blk[i, (i + s) % Z] != 0):
+                    return None
+            row.append(tuple(int(s) for s in hot))
+        blocks.append(row)
+    return QCCode(Z, blocks)
+
+
+def detect_qc(H, candidates=None):
+    """Largest circulant size Z for which H is block-circulant and the kernels'
+    limits hold (mb * roundup(Z, 64) <= 1024 threads), or None."""
+    H = np.asarray(H)
+    m, n = H.shape
+    if candidates is None:
+        g = int(np.gcd(m, n))
+        candidates = [z for z in range(g, 7, -1) if g % z == 0]
+    for Z in candidates:
+        if m % Z or n % Z:
+            continue
+        if (m // Z) * ((Z + 63) // 64 * 64) > 1024 or -(-(n // Z) // (m // Z)) > 32:
+            continue
+        qc = dense_to_qc(H, Z)
+        if qc is not None:
+            return qc
+    return None
+
+
+def dense_to_csr(H):
+    """(m, n, row_ptr int32[m+1], col_idx int32[E]) with ascending columns per row,
+    the adjacency ldpcDecoder.__init__ derives with np.where (ldpc.py:237-247)."""
+    H = np.asarray(H)
+    m, n = H.shape
+    rows, cols = np.nonzero(H)
+    row_ptr = np.zeros(m + 1, np.int64)
+    np.add.at(row_ptr, rows + 1, 1)
+    return m, n, np.cumsum(row_ptr).astype(np.int32), cols.astype(np.int32)
+
+
+def hot_locations_to_circulant(locations, Z, dtype=np.int32):
+    """Z x Z circulant with ones at (i, (i + loc) mod Z) (fileHandler.py:137-142)."""
+    C = np.zeros((Z, Z), dtype=dtype)
+    i = np.arange(Z)
+    for s in locations:
+        C[i, (i + int(s)) % Z] = 1
+    return C
+
+
+def parse_hot_position_file(path, dim0, dim1, Z):
+    """QCCode from a text file with one circulant per line ("a, b, ..." = hot
+    positions of its first row), block-row after block-row -- the layout
+    fileHandler.readMatrixFromFile(..., isGenerator=False) reads
+    (fileHandler.py:161-181; that function only handles two block-rows, this
+    one handles dim0 // Z)."""
+    with open(path) as fid:
+        lines = [ln.strip() for ln in fid.readlines() if ln.strip()]
+    mb, nb = dim0 // Z, dim1 // Z
+    if len(lines) < mb * nb:
+        raise ValueError(f'{path}: expected {mb * nb} lines, found {len(lines)}')
+    blocks = [[tuple(sorted(set(int(t) for t in lines[b * nb + j].split(',') if t.strip() != '')))
+               for j in range(nb)] for b in range(mb)]
+    return QCCode(Z, blocks)

@@ -1,0 +1,1081 @@
+// libldpc_hip.so -- LDPC code evaluation for AMD MI355X (gfx950, CDNA4).
+//
+// One workgroup decodes one frame (or a few short frames) entirely on chip:
+//   * posteriors of all n variable nodes live in LDS,
+//   * every check row keeps its outgoing messages in compressed form
+//     {min1, min2, argmin, sign bits} (plain min-sum sends only two distinct
+//     magnitudes per row, ldpc.py:190-191) -- in registers of the thread that
+//     owns the row and, for the variable update, in a small LDS array,
+//   * the parity syndrome of the previous posterior is a by-product of the
+//     check pass (the hard decisions of the values it gathers anyway).
+// Quasi-cyclic structure is used for addressing: thread i of block-row b reads
+// posterior (i + s) mod Z of block-column j, so a wavefront touches 64
+// consecutive LDS words per circulant shift.
+//
+// Floating-point evaluation order follows the reference decoder exactly
+// (ldpc.py:150-163, 174-202, 295-324); build with -ffp-contract=off.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include <string.h>
+#include <math.h>
+#include <vector>
+#include <algorithm>
+#include <new>
+
+#include "../../include/ldpc_hip.h"
+
+// ---------------------------------------------------------------- errors
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                              \
+    do {                                                                           \
+        hipError_t e_ = (expr);                                                    \
+        if (e_ != hipSuccess)                                                      \
+            return fail(LDPC_E_DEVICE, "%s failed: %s (%s:%d)", #expr,            \
+                        hipGetErrorString(e_), __FILE__, __LINE__);                \
+    } while (0)
+
+// ---------------------------------------------------------------- device tables
+struct QcTables {
+    int Z, Zp, mb, nb, m, n;
+    const int32_t *row_ptr;  // [mb+1] entry ranges of each block-row
+    const int2 *row_ent;     // {j*Z, s}: row i has an edge to column j*Z + (i+s) mod Z
+    const int32_t *col_ptr;  // [nb+1] group ranges of each block-column
+    const int4 *col_grp;     // {b, w, first entry, -}: one non-empty block (b, j), ascending b
+    const int2 *col_ent;     // {s, e}: shift and edge number inside row list of b; s descending
+};
+
+struct CsrTables {
+    int m, n, E;
+    const int32_t *row_ptr;  // [m+1]
+    const int32_t *col_idx;  // [E]
+    const int32_t *col_ptr;  // [n+1]
+    const int32_t *col_row;  // [E] rows of each column, ascending
+    const int32_t *col_e;    // [E] edge number of that entry inside its row
+};
+
+struct DecodeArgs {
+    const void *llr;       // [frames][n] float32, or float64 if llr_f64
+    int llr_f64;
+    float llr_scale;
+    int64_t n_frames;
+    int max_iters;
+    int sign_mode;
+    uint8_t *hard;         // [frames][ceil(n/8)] or null
+    int32_t *iters;        // [frames] or null
+    uint8_t *conv;         // [frames] or null
+    int32_t *ones;         // [frames] or null
+    void *soft;            // [frames][n] T or null
+};
+
+// ---------------------------------------------------------------- small helpers
+template <typename T> struct Vec2;
+template <> struct Vec2<float> { typedef float2 type; };
+template <> struct Vec2<double> { typedef double2 type; };
+
+template <bool S64> struct SignBits;
+template <> struct SignBits<false> {
+    typedef uint32_t type;
+    struct __attribute__((aligned(8))) Meta { uint32_t signs; uint32_t idx; };
+};
+template <> struct SignBits<true> {
+    typedef uint64_t type;
+    struct __attribute__((aligned(16))) Meta { uint64_t signs; uint32_t idx; uint32_t pad; };
+};
+
+__device__ __forceinline__ float with_sign(float mag, uint32_t neg)
+{
+    return __uint_as_float(__float_as_uint(mag) | (neg << 31));
+}
+__device__ __forceinline__ double with_sign(double mag, uint32_t neg)
+{
+    return __hiloint2double(__double2hiint(mag) | (int)(neg << 31), __double2loint(mag));
+}
+// channel value (frame-major) as the arithmetic type T
+template <typename T>
+__device__ __forceinline__ T load_llr(const void *llr, int is_f64, int64_t idx)
+{
+    return is_f64 ? T(reinterpret_cast<const double *>(llr)[idx])
+                  : T(reinterpret_cast<const float *>(llr)[idx]);
+}
+__device__ __forceinline__ float t_inf(float) { return __uint_as_float(0x7f800000u); }
+__device__ __forceinline__ double t_inf(double) { return __hiloint2double(0x7ff00000, 0); }
+__device__ __forceinline__ float t_abs(float x) { return fabsf(x); }
+__device__ __forceinline__ double t_abs(double x) { return fabs(x); }
+
+// second-smallest update: new min2 given min1 <= min2 and a candidate a
+__device__ __forceinline__ float t_mid(float min1, float min2, float a)
+{
+    return __builtin_amdgcn_fmed3f(min1, min2, a);
+}
+__device__ __forceinline__ double t_mid(double min1, double min2, double a)
+{
+    return fmin(min2, fmax(min1, a));
+}
+__device__ __forceinline__ float t_min(float a, float b) { return fminf(a, b); }
+__device__ __forceinline__ double t_min(double a, double b) { return fmin(a, b); }
+
+template <typename ST> __device__ __forceinline__ uint32_t parity_of(ST x);
+template <> __device__ __forceinline__ uint32_t parity_of<uint32_t>(uint32_t x) { return __popc(x) & 1u; }
+template <> __device__ __forceinline__ uint32_t parity_of<uint64_t>(uint64_t x) { return __popcll(x) & 1u; }
+
+// message a check row sends along its edge e, rebuilt from the row's compressed state
+template <typename T, bool S64>
+__device__ __forceinline__ T rebuild(const typename Vec2<T>::type mm,
+                                     const typename SignBits<S64>::Meta mt, int e)
+{
+    const T mag = (mt.idx == (uint32_t)e) ? mm.y : mm.x;
+    return with_sign(mag, (uint32_t)((mt.signs >> e) & 1u));
+}
+
+// ---------------------------------------------------------------- QC min-sum kernel
+//
+// Thread layout: blockDim = FPW * mb * Zp, Zp = roundup(Z, 64).  Thread
+// t = ((f*mb + g)*Zp + i) serves, for frame slot f,
+//   check pass:    row (block-row g, i)                              (i < Z)
+//   variable pass: columns (block-col j, i) for j = g, g+mb, g+2mb... (< nb)
+// g and f are wavefront-uniform, so all table look-ups are scalar loads.
+//
+// Restates ldpcDecoder.decoderMainLoop (ldpc.py:326-337): syndrome of the
+// channel hard decision first; then per iteration variableNodesToCheckNodes +
+// calcOutgoingValues (check pass) and checkNodesToVariableNodes + channel add
+// (variable pass); the syndrome of iteration k's posterior is evaluated by the
+// check pass of iteration k+1, whose other results are dropped if it is zero.
+template <typename T, bool S64, int CPT, int FPW>
+__global__ void __launch_bounds__(1024)
+qc_minsum_kernel(const QcTables tb, const DecodeArgs a)
+{
+    typedef typename Vec2<T>::type T2;
+    typedef typename SignBits<S64>::type ST;
+    typedef typename SignBits<S64>::Meta Meta;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int Z = tb.Z, Zp = tb.Zp, mb = tb.mb, nb = tb.nb, n = tb.n;
+    const int slots = FPW * mb * Zp;
+    // carve (all offsets multiples of 16)
+    size_t off = 0;
+    T *post = reinterpret_cast<T *>(smem + off);
+    off += (((size_t)FPW * n * sizeof(T)) + 15) & ~(size_t)15;
+    T2 *mins = reinterpret_cast<T2 *>(smem + off);
+    off += (size_t)slots * sizeof(T2);
+    Meta *meta = reinterpret_cast<Meta *>(smem + off);
+    off += (size_t)slots * sizeof(Meta);
+    int *flags = reinterpret_cast<int *>(smem + off);   // [2][FPW] "syndrome non-zero"
+    int *ones_cnt = flags + 2 * FPW;                    // [FPW]
+
+    const int tid = threadIdx.x;
+    const int grp = __builtin_amdgcn_readfirstlane(tid / Zp);
+    const int f = grp / mb;          // frame slot inside the workgroup
+    const int g = grp - f * mb;      // block-row served / first block-column served
+    const int i = tid - grp * Zp;
+    const bool live = i < Z;
+    const int fbase = f * n;         // start of this frame's posteriors in LDS
+    const int slot = grp * Zp + i;   // this row's slot in mins/meta
+    const int re0 = tb.row_ptr[g];
+    const int deg = tb.row_ptr[g + 1] - re0;
+    const int nbytes = (n + 7) >> 3;
+    const T INF = t_inf(T(0));
+
+    const int64_t n_fblocks = (a.n_frames + FPW - 1) / FPW;
+    for (int64_t fb = blockIdx.x; fb < n_fblocks; fb += gridDim.x) {
+        const int64_t frame = fb * FPW + f;
+        const bool valid = frame < a.n_frames;
+
+        // ---- load channel values; posterior := channel (decoderSet, ldpc.py:270-274)
+        T y[CPT];
+#pragma unroll
+        for (int q = 0; q < CPT; ++q) {
+            const int j = g + q * mb;
+            y[q] = T(0);
+            if (j < nb && live && valid) {
+                // "+ 0" turns a -0.0 input into +0.0: no effect on any comparison or sum
+                // below, and it keeps "sign bit set" equivalent to "< 0" for every message.
+                y[q] = load_llr<T>(a.llr, a.llr_f64, frame * n + j * Z + i) * T(a.llr_scale) + T(0);
+                post[fbase + j * Z + i] = y[q];
+            }
+        }
+        if (tid < 3 * FPW) flags[tid] = 0;
+        // fresh check nodes: every outgoing message is +0 (checkNode.__init__, ldpc.py:121)
+        T omin1 = T(0), omin2 = T(0);
+        ST osigns = 0;
+        uint32_t oidx = 0;
+        uint32_t act_mask = 0;       // frame slots still iterating (same value in every thread)
+#pragma unroll
+        for (int ff = 0; ff < FPW; ++ff)
+            if (fb * FPW + ff < a.n_frames) act_mask |= 1u << ff;
+        int my_iters = 0;
+        int my_conv = 0;
+        __syncthreads();
+
+        for (int it = 0;; ++it) {
+            const bool active = (act_mask >> f) & 1u;
+            const int par = it & 1;
+            // ================= check pass (+ syndrome of the current posterior)
+            if (active && live) {
+                T min1 = INF, min2 = INF;
+                uint32_t idx = 0;
+                ST ns = 0;
+                unsigned long long synd = 0;
+#pragma unroll 4
+                for (int e = 0; e < deg; ++e) {
+                    const int2 ent = tb.row_ent[re0 + e];
+                    uint32_t c = (uint32_t)(i + ent.y);
+                    c = min(c, c - (uint32_t)Z);                 // (i + s) mod Z
+                    const T p = post[fbase + ent.x + (int)c];
+                    synd ^= __ballot(p > T(0));                  // slicer, ldpc.py:47
+                    const T mag_old = (oidx == (uint32_t)e) ? omin2 : omin1;
+                    const T c_old = with_sign(mag_old, (uint32_t)((osigns >> e) & 1u));
+                    const T v = p - c_old;                       // receive, ldpc.py:161
+                    const uint32_t neg = v < T(0);               // setSign, ldpc.py:139
+                    ns |= (ST)neg << e;
+                    const T av = t_abs(v);                       // ldpc.py:178
+                    const bool lt = av < min1;
+                    min2 = t_mid(min1, min2, av);
+                    idx = lt ? (uint32_t)e : idx;
+                    min1 = t_min(min1, av);
+                }
+                // sign of every outgoing message = (product of all signs) * own sign, ldpc.py:190
+                uint32_t S = parity_of<ST>(ns);
+                if (a.sign_mode == LDPC_SIGN_CORRECTED) S ^= (uint32_t)deg & 1u;
+                const ST full = (deg >= (int)(8 * sizeof(ST))) ? ~(ST)0 : ((((ST)1) << deg) - 1);
+                ns ^= S ? full : (ST)0;
+                omin1 = min1; omin2 = min2; osigns = ns; oidx = idx;
+                T2 mm; mm.x = min1; mm.y = min2;
+                mins[slot] = mm;
+                Meta mt; mt.signs = ns; mt.idx = idx;
+                meta[slot] = mt;
+                if (synd != 0ull) flags[par * FPW + f] = 1;
+            }
+            __syncthreads();
+            // ================= stop test (ldpc.py:332-335), identical in every thread
+            uint32_t next_mask = 0;
+#pragma unroll
+            for (int ff = 0; ff < FPW; ++ff) {
+                if ((act_mask >> ff) & 1u) {
+                    const int bad = flags[par * FPW + ff];
+                    if (bad != 0 && it < a.max_iters) {
+                        next_mask |= 1u << ff;
+                    } else if (ff == f) {
+                        my_iters = it;
+                        my_conv = (bad == 0);
+                    }
+                }
+            }
+            act_mask = next_mask;
+            if (act_mask == 0) break;
+            if (tid < FPW) flags[(par ^ 1) * FPW + tid] = 0;
+            // ================= variable pass (ldpc.py:295-311, 321-323)
+            if (((act_mask >> f) & 1u) && live) {
+#pragma unroll
+                for (int q = 0; q < CPT; ++q) {
+                    const int j = g + q * mb;
+                    if (j < nb) {
+                        T acc = T(0);
+                        const int g0 = tb.col_ptr[j], g1 = tb.col_ptr[j + 1];
+                        for (int gi = g0; gi < g1; ++gi) {
+                            const int4 cg = tb.col_grp[gi];
+                            const int rbase = (f * mb + cg.x) * Zp;
+                            const int2 *ent = tb.col_ent + cg.z;
+                            if (cg.y == 1) {
+                                const int2 en = ent[0];
+                                uint32_t r = (uint32_t)(i - en.x);
+                                r = min(r, r + (uint32_t)Z);
+                                acc = acc + rebuild<T, S64>(mins[rbase + (int)r], meta[rbase + (int)r], en.y);
+                            } else if (cg.y == 2) {
+                                const int2 hi = ent[0], lo = ent[1];     // hi.x > lo.x
+                                uint32_t rh = (uint32_t)(i - hi.x); rh = min(rh, rh + (uint32_t)Z);
+                                uint32_t rl = (uint32_t)(i - lo.x); rl = min(rl, rl + (uint32_t)Z);
+                                const T vh = rebuild<T, S64>(mins[rbase + (int)rh], meta[rbase + (int)rh], hi.y);
+                                const T vl = rebuild<T, S64>(mins[rbase + (int)rl], meta[rbase + (int)rl], lo.y);
+                                // smaller row index first: the low shift's row comes first
+                                // exactly when lo.x <= i < hi.x
+                                const bool lo_first = (i >= lo.x) && (i < hi.x);
+                                acc = acc + (lo_first ? vl : vh);
+                                acc = acc + (lo_first ? vh : vl);
+                            } else {
+                                // shifts descending: rows i - s (s <= i) ascend, then rows i - s + Z (s > i) ascend
+                                for (int k = 0; k < cg.y; ++k) {
+                                    const int2 en = ent[k];
+                                    if (en.x <= i)
+                                        acc = acc + rebuild<T, S64>(mins[rbase + i - en.x], meta[rbase + i - en.x], en.y);
+                                }
+                                for (int k = 0; k < cg.y; ++k) {
+                                    const int2 en = ent[k];
+                                    if (en.x > i)
+                                        acc = acc + rebuild<T, S64>(mins[rbase + i - en.x + Z], meta[rbase + i - en.x + Z], en.y);
+                                }
+                            }
+                        }
+                        post[fbase + j * Z + i] = acc + y[q];            // channel last, ldpc.py:322
+                    }
+                }
+            }
+            __syncthreads();
+        }
+
+        // ================= outputs
+        for (int x = tid; x < FPW * nbytes; x += blockDim.x) {
+            const int ff = x / nbytes;
+            const int qb = x - ff * nbytes;
+            const int64_t fr = fb * FPW + ff;
+            if (fr < a.n_frames) {
+                uint32_t byte = 0;
+                const int c0 = qb * 8;
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (c0 + k < n) byte |= (uint32_t)(post[ff * n + c0 + k] > T(0)) << k;
+                if (a.hard) a.hard[fr * nbytes + qb] = (uint8_t)byte;
+                if (byte) atomicAdd(&ones_cnt[ff], (int)__popc(byte));
+            }
+        }
+        if (a.soft && valid && live) {
+            T *so = reinterpret_cast<T *>(a.soft) + frame * n;
+#pragma unroll
+            for (int q = 0; q < CPT; ++q) {
+                const int j = g + q * mb;
+                if (j < nb) so[j * Z + i] = post[fbase + j * Z + i];
+            }
+        }
+        __syncthreads();
+        if (valid && g == 0 && i == 0) {
+            if (a.iters) a.iters[frame] = my_iters;
+            if (a.conv) a.conv[frame] = (uint8_t)my_conv;
+            if (a.ones) a.ones[frame] = ones_cnt[f];
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------- CSR min-sum kernel
+//
+// Arbitrary sparse H.  One 256-thread workgroup per frame; posteriors and the
+// compressed row states live in a per-workgroup slice of a global workspace
+// (they stay in L2 for the sizes this path is used for).  Same arithmetic as
+// the QC kernel.
+template <typename T>
+__global__ void __launch_bounds__(256)
+csr_minsum_kernel(const CsrTables tb, const DecodeArgs a, unsigned char *workspace, size_t ws_stride)
+{
+    typedef typename Vec2<T>::type T2;
+    typedef typename SignBits<true>::Meta Meta;
+    __shared__ int flags[2];
+    __shared__ int ones_cnt;
+    __shared__ int result[2];
+    const int m = tb.m, n = tb.n;
+    unsigned char *ws = workspace + (size_t)blockIdx.x * ws_stride;
+    T *post = reinterpret_cast<T *>(ws);
+    T *ych = post + n;
+    size_t off = (((size_t)2 * n * sizeof(T)) + 15) & ~(size_t)15;
+    T2 *mins = reinterpret_cast<T2 *>(ws + off);
+    off += (size_t)m * sizeof(T2);
+    Meta *meta = reinterpret_cast<Meta *>(ws + off);
+    const int tid = threadIdx.x;
+    const int nbytes = (n + 7) >> 3;
+    const T INF = t_inf(T(0));
+
+    for (int64_t frame = blockIdx.x; frame < a.n_frames; frame += gridDim.x) {
+        for (int c = tid; c < n; c += blockDim.x) {
+            const T yv = load_llr<T>(a.llr, a.llr_f64, frame * n + c) * T(a.llr_scale) + T(0);
+            ych[c] = yv;
+            post[c] = yv;
+        }
+        for (int r = tid; r < m; r += blockDim.x) {
+            T2 z; z.x = T(0); z.y = T(0);
+            mins[r] = z;
+            Meta mt; mt.signs = 0; mt.idx = 0; mt.pad = 0;
+            meta[r] = mt;
+        }
+        if (tid < 2) flags[tid] = 0;
+        if (tid == 0) ones_cnt = 0;
+        __syncthreads();
+        int it = 0;
+        for (;; ++it) {
+            const int par = it & 1;
+            bool bad_row = false;
+            for (int r = tid; r < m; r += blockDim.x) {
+                const int e0 = tb.row_ptr[r], e1 = tb.row_ptr[r + 1];
+                const T2 om = mins[r];
+                const Meta ot = meta[r];
+                T min1 = INF, min2 = INF;
+                uint32_t idx = 0, sy = 0;
+                uint64_t ns = 0;
+                for (int e = e0; e < e1; ++e) {
+                    const int k = e - e0;
+                    const T p = post[tb.col_idx[e]];
+                    sy ^= (uint32_t)(p > T(0));
+                    const T v = p - rebuild<T, true>(om, ot, k);
+                    ns |= (uint64_t)(v < T(0)) << k;
+                    const T av = t_abs(v);
+                    const bool lt = av < min1;
+                    min2 = t_mid(min1, min2, av);
+                    idx = lt ? (uint32_t)k : idx;
+                    min1 = t_min(min1, av);
+                }
+                const int deg = e1 - e0;
+                uint32_t S = parity_of<uint64_t>(ns);
+                if (a.sign_mode == LDPC_SIGN_CORRECTED) S ^= (uint32_t)deg & 1u;
+                const uint64_t full = (deg >= 64) ? ~0ull : ((1ull << deg) - 1);
+                ns ^= S ? full : 0ull;
+                T2 mm; mm.x = min1; mm.y = min2;
+                mins[r] = mm;
+                Meta mt; mt.signs = ns; mt.idx = idx; mt.pad = 0;
+                meta[r] = mt;
+                bad_row |= (sy != 0);
+            }
+            if (bad_row) flags[par] = 1;
+            __syncthreads();
+            const int bad = flags[par];
+            if (bad == 0 || it >= a.max_iters) {
+                if (tid == 0) { result[0] = it; result[1] = (bad == 0); }
+                break;
+            }
+            if (tid == 0) flags[par ^ 1] = 0;
+            for (int c = tid; c < n; c += blockDim.x) {
+                T acc = T(0);
+                for (int k = tb.col_ptr[c]; k < tb.col_ptr[c + 1]; ++k) {
+                    const int r = tb.col_row[k];
+                    acc = acc + rebuild<T, true>(mins[r], meta[r], tb.col_e[k]);
+                }
+                post[c] = acc + ych[c];
+            }
+            __syncthreads();
+        }
+        for (int qb = tid; qb < nbytes; qb += blockDim.x) {
+            uint32_t byte = 0;
+            for (int k = 0; k < 8; ++k)
+                if (qb * 8 + k < n) byte |= (uint32_t)(post[qb * 8 + k] > T(0)) << k;
+            if (a.hard) a.hard[frame * nbytes + qb] = (uint8_t)byte;
+            if (byte) atomicAdd(&ones_cnt, (int)__popc(byte));
+        }
+        if (a.soft) {
+            T *so = reinterpret_cast<T *>(a.soft) + frame * n;
+            for (int c = tid; c < n; c += blockDim.x) so[c] = post[c];
+        }
+        __syncthreads();
+        if (tid == 0) {
+            if (a.iters) a.iters[frame] = result[0];
+            if (a.conv) a.conv[frame] = (uint8_t)result[1];
+            if (a.ones) a.ones[frame] = ones_cnt;
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------- channel kernel
+__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+        c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
+        k.x += 0x9E3779B9u;
+        k.y += 0xBB67AE85u;
+    }
+    return c;
+}
+
+__device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+
+// Four standard normals for positions 4*q .. 4*q+3 of frame `frame`.
+__device__ __forceinline__ float4 normal4(uint64_t seed, uint64_t frame, uint32_t q, uint32_t stream)
+{
+    const uint4 r = philox4x32_10(make_uint4(q, (uint32_t)frame, (uint32_t)(frame >> 32), stream),
+                                  make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
+    const float r0 = sqrtf(-2.0f * logf(u01(r.x)));
+    const float r1 = sqrtf(-2.0f * logf(u01(r.z)));
+    float s0, c0, s1, c1;
+    sincospif(2.0f * u01(r.y), &s0, &c0);
+    sincospif(2.0f * u01(r.w), &s1, &c1);
+    return make_float4(r0 * c0, r0 * s0, r1 * c1, r1 * s1);
+}
+
+// y = -1 + sigma*z for the all-zero codeword (modulate: 0 -> -1, ldpc.py:62-66;
+// addAWGN, ldpc.py:51-60).  One workgroup per frame; per-frame sigma_hat
+// (ldpc.py:58) and channel hard-decision errors (ldpcCUDA.py:586-587).
+__global__ void __launch_bounds__(256)
+channel_awgn_kernel(uint64_t seed, uint32_t stream, uint64_t first_frame, int64_t n_frames, int n,
+                    float sigma, float *llr, float *sigma_hat, int32_t *uncoded)
+{
+    __shared__ float s_sum[4];
+    __shared__ int s_err[4];
+    const int tid = threadIdx.x;
+    const int nq = (n + 3) >> 2;
+    for (int64_t f = blockIdx.x; f < n_frames; f += gridDim.x) {
+        float sum = 0.f;
+        int err = 0;
+        float *out = llr + f * n;
+        for (int q = tid; q < nq; q += blockDim.x) {
+            const float4 z = normal4(seed, first_frame + (uint64_t)f, (uint32_t)q, stream);
+            const float nz[4] = {sigma * z.x, sigma * z.y, sigma * z.z, sigma * z.w};
+            float yv[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                yv[k] = -1.0f + nz[k];
+                if (4 * q + k < n) {
+                    sum += nz[k] * nz[k];
+                    err += yv[k] > 0.f;
+                }
+            }
+            if (4 * q + 3 < n && ((((uintptr_t)(out + 4 * q)) & 15) == 0)) {
+                *reinterpret_cast<float4 *>(out + 4 * q) = make_float4(yv[0], yv[1], yv[2], yv[3]);
+            } else {
+                for (int k = 0; k < 4; ++k)
+                    if (4 * q + k < n) out[4 * q + k] = yv[k];
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            sum += __shfl_down(sum, o);
+            err += __shfl_down(err, o);
+        }
+        if ((tid & 63) == 0) { s_sum[tid >> 6] = sum; s_err[tid >> 6] = err; }
+        __syncthreads();
+        if (tid == 0) {
+            const float t = (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]);
+            if (sigma_hat) sigma_hat[f] = sqrtf(t / (float)n);
+            if (uncoded) uncoded[f] = s_err[0] + s_err[1] + s_err[2] + s_err[3];
+        }
+        __syncthreads();
+    }
+}
+
+// counters[6]: frames, frame errors, decoded bit errors, iterations, uncoded bit errors, not-a-codeword
+__global__ void __launch_bounds__(256)
+accumulate_kernel(int64_t n_frames, const int32_t *iters, const uint8_t *conv, const int32_t *ones,
+                  const int32_t *uncoded, const float *sigma_hat,
+                  unsigned long long *counters, float *per_frame)
+{
+    unsigned long long c[6] = {0, 0, 0, 0, 0, 0};
+    for (int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; f < n_frames;
+         f += (int64_t)gridDim.x * blockDim.x) {
+        c[0] += 1;
+        c[1] += ones[f] != 0;
+        c[2] += (unsigned long long)ones[f];
+        c[3] += (unsigned long long)iters[f];
+        c[4] += (unsigned long long)uncoded[f];
+        c[5] += conv[f] == 0;
+        if (per_frame) {
+            float *p = per_frame + 4 * f;
+            p[0] = sigma_hat[f];
+            p[1] = (float)uncoded[f];
+            p[2] = (float)ones[f];
+            p[3] = (float)iters[f];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        unsigned long long v = c[k];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd(&counters[k], v);
+    }
+}
+
+// ---------------------------------------------------------------- handle
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes)
+    {
+        if (bytes <= cap) return 0;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) { p = nullptr; return fail(LDPC_E_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); }
+        cap = bytes;
+        return 0;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct ldpc_handle {
+    int device = 0;
+    int n_cu = 0;
+    size_t lds_max = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    bool is_qc = false;
+    int m = 0, n = 0, E = 0, max_row_deg = 0;
+    // QC
+    QcTables qc{};
+    int cols_per_thread = 0;
+    // CSR
+    CsrTables csr{};
+    std::vector<void *> tables;   // device allocations owned by the handle
+    // staging for the host entry points
+    DevBuf b_llr, b_hard, b_iters, b_conv, b_ones, b_soft, b_sig, b_unc, b_cnt, b_pf, b_ws;
+};
+
+struct Launch {
+    const void *fn = nullptr;
+    int grid = 0, block = 0, fpw = 1;
+    size_t lds = 0;
+};
+
+template <typename H> static int upload(ldpc_handle *h, const std::vector<H> &v, const H **out)
+{
+    void *d = nullptr;
+    const size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(H);
+    HIP_TRY(hipMalloc(&d, bytes));
+    h->tables.push_back(d);
+    if (!v.empty()) HIP_TRY(hipMemcpy(d, v.data(), v.size() * sizeof(H), hipMemcpyHostToDevice));
+    *out = reinterpret_cast<const H *>(d);
+    return 0;
+}
+
+static int open_device(int device, ldpc_handle *h)
+{
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0)
+        return fail(LDPC_E_DEVICE, "no HIP device available (this library has no CPU fallback)");
+    if (device < 0 || device >= cnt) return fail(LDPC_E_ARG, "device %d out of range (%d visible)", device, cnt);
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    h->device = device;
+    h->n_cu = prop.multiProcessorCount;
+    h->lds_max = prop.sharedMemPerBlock;
+    HIP_TRY(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+    h->stream = h->own_stream;
+    return 0;
+}
+
+extern "C" const char *ldpc_last_error(void) { return g_err; }
+
+extern "C" int ldpc_device_count(void)
+{
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess) return 0;
+    return cnt;
+}
+
+extern "C" void ldpc_destroy(ldpc_handle *h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->own_stream) { (void)hipStreamSynchronize(h->own_stream); }
+    for (void *p : h->tables) (void)hipFree(p);
+    DevBuf *bufs[] = {&h->b_llr, &h->b_hard, &h->b_iters, &h->b_conv, &h->b_ones, &h->b_soft,
+                      &h->b_sig, &h->b_unc, &h->b_cnt, &h->b_pf, &h->b_ws};
+    for (DevBuf *b : bufs) b->release();
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    delete h;
+}
+
+extern "C" int ldpc_create_qc(int device, int Z, int mb, int nb, const int32_t *blk_ptr,
+                              const int32_t *shifts, ldpc_handle **out)
+{
+    if (!out) return fail(LDPC_E_ARG, "out is NULL");
+    *out = nullptr;
+    if (Z <= 0 || mb <= 0 || nb <= 0 || !blk_ptr) return fail(LDPC_E_ARG, "bad QC dimensions");
+    const int nblk = mb * nb;
+    if (blk_ptr[0] != 0) return fail(LDPC_E_ARG, "blk_ptr[0] must be 0");
+    for (int k = 0; k < nblk; ++k)
+        if (blk_ptr[k + 1] < blk_ptr[k]) return fail(LDPC_E_ARG, "blk_ptr must be non-decreasing");
+    if (blk_ptr[nblk] > 0 && !shifts) return fail(LDPC_E_ARG, "shifts is NULL");
+    const int Zp = (Z + 63) / 64 * 64;
+    if ((long long)mb * Zp > 1024)
+        return fail(LDPC_E_UNSUPPORTED, "mb*roundup(Z,64) = %lld exceeds 1024 threads", (long long)mb * Zp);
+    if ((nb + mb - 1) / mb > 32)
+        return fail(LDPC_E_UNSUPPORTED, "more than 32 block-columns per block-row group");
+
+    std::vector<int32_t> row_ptr(mb + 1, 0), col_ptr(nb + 1, 0);
+    std::vector<int2> row_ent, col_ent;
+    std::vector<int4> col_grp;
+    // edge number of shift k of block (b, j) inside the row list of block-row b
+    std::vector<int> edge_no(blk_ptr[nblk] > 0 ? blk_ptr[nblk] : 1, 0);
+    int max_deg = 0;
+    for (int b = 0; b < mb; ++b) {
+        int cnt = 0;
+        for (int j = 0; j < nb; ++j) {
+            const int k0 = blk_ptr[b * nb + j], k1 = blk_ptr[b * nb + j + 1];
+            for (int k = k0; k < k1; ++k) {
+                const int s = shifts[k];
+                if (s < 0 || s >= Z) return fail(LDPC_E_ARG, "shift %d out of range [0,%d)", s, Z);
+                for (int k2 = k0; k2 < k; ++k2)
+                    if (shifts[k2] == s) return fail(LDPC_E_ARG, "duplicate shift %d in block (%d,%d)", s, b, j);
+                edge_no[k] = cnt++;
+                row_ent.push_back(make_int2(j * Z, s));
+            }
+        }
+        row_ptr[b + 1] = (int)row_ent.size();
+        max_deg = std::max(max_deg, cnt);
+    }
+    if (max_deg > 64) return fail(LDPC_E_UNSUPPORTED, "check degree %d exceeds 64", max_deg);
+    for (int j = 0; j < nb; ++j) {
+        for (int b = 0; b < mb; ++b) {
+            const int k0 = blk_ptr[b * nb + j], k1 = blk_ptr[b * nb + j + 1];
+            if (k1 == k0) continue;
+            std::vector<int2> ent;
+            for (int k = k0; k < k1; ++k) ent.push_back(make_int2(shifts[k], edge_no[k]));
+            std::sort(ent.begin(), ent.end(), [](const int2 &x, const int2 &y) { return x.x > y.x; });
+            col_grp.push_back(make_int4(b, k1 - k0, (int)col_ent.size(), 0));
+            col_ent.insert(col_ent.end(), ent.begin(), ent.end());
+        }
+        col_ptr[j + 1] = (int)col_grp.size();
+    }
+
+    ldpc_handle *h = new (std::nothrow) ldpc_handle();
+    if (!h) return fail(LDPC_E_NOMEM, "out of host memory");
+    int rc = open_device(device, h);
+    if (rc) { delete h; return rc; }
+    h->is_qc = true;
+    h->m = mb * Z; h->n = nb * Z; h->E = blk_ptr[nblk] * Z; h->max_row_deg = max_deg;
+    h->cols_per_thread = (nb + mb - 1) / mb;
+    h->qc.Z = Z; h->qc.Zp = Zp; h->qc.mb = mb; h->qc.nb = nb; h->qc.m = h->m; h->qc.n = h->n;
+    if ((rc = upload(h, row_ptr, &h->qc.row_ptr)) || (rc = upload(h, row_ent, &h->qc.row_ent)) ||
+        (rc = upload(h, col_ptr, &h->qc.col_ptr)) || (rc = upload(h, col_grp, &h->qc.col_grp)) ||
+        (rc = upload(h, col_ent, &h->qc.col_ent))) {
+        ldpc_destroy(h);
+        return rc;
+    }
+    *out = h;
+    return 0;
+}
+
+extern "C" int ldpc_create_csr(int device, int m, int n, const int32_t *row_ptr,
+                               const int32_t *col_idx, ldpc_handle **out)
+{
+    if (!out) return fail(LDPC_E_ARG, "out is NULL");
+    *out = nullptr;
+    if (m <= 0 || n <= 0 || !row_ptr) return fail(LDPC_E_ARG, "bad CSR dimensions");
+    if (row_ptr[0] != 0) return fail(LDPC_E_ARG, "row_ptr[0] must be 0");
+    int max_deg = 0;
+    for (int r = 0; r < m; ++r) {
+        if (row_ptr[r + 1] < row_ptr[r]) return fail(LDPC_E_ARG, "row_ptr must be non-decreasing");
+        max_deg = std::max(max_deg, row_ptr[r + 1] - row_ptr[r]);
+    }
+    const int E = row_ptr[m];
+    if (E > 0 && !col_idx) return fail(LDPC_E_ARG, "col_idx is NULL");
+    if (max_deg > 64) return fail(LDPC_E_UNSUPPORTED, "check degree %d exceeds 64", max_deg);
+    for (int r = 0; r < m; ++r)
+        for (int e = row_ptr[r]; e < row_ptr[r + 1]; ++e) {
+            if (col_idx[e] < 0 || col_idx[e] >= n) return fail(LDPC_E_ARG, "column index out of range");
+            if (e > row_ptr[r] && col_idx[e] <= col_idx[e - 1])
+                return fail(LDPC_E_ARG, "col_idx must be strictly ascending inside a row");
+        }
+    std::vector<int32_t> rp(row_ptr, row_ptr + m + 1), ci(col_idx, col_idx + E);
+    std::vector<int32_t> cp(n + 1, 0), crow(E), ce(E);
+    for (int e = 0; e < E; ++e) cp[ci[e] + 1]++;
+    for (int c = 0; c < n; ++c) cp[c + 1] += cp[c];
+    std::vector<int32_t> fill(cp.begin(), cp.end() - 1);
+    for (int r = 0; r < m; ++r)          // ascending rows => ascending rows inside each column
+        for (int e = rp[r]; e < rp[r + 1]; ++e) {
+            const int pos = fill[ci[e]]++;
+            crow[pos] = r;
+            ce[pos] = e - rp[r];
+        }
+    ldpc_handle *h = new (std::nothrow) ldpc_handle();
+    if (!h) return fail(LDPC_E_NOMEM, "out of host memory");
+    int rc = open_device(device, h);
+    if (rc) { delete h; return rc; }
+    h->is_qc = false;
+    h->m = m; h->n = n; h->E = E; h->max_row_deg = max_deg;
+    h->csr.m = m; h->csr.n = n; h->csr.E = E;
+    if ((rc = upload(h, rp, &h->csr.row_ptr)) || (rc = upload(h, ci, &h->csr.col_idx)) ||
+        (rc = upload(h, cp, &h->csr.col_ptr)) || (rc = upload(h, crow, &h->csr.col_row)) ||
+        (rc = upload(h, ce, &h->csr.col_e))) {
+        ldpc_destroy(h);
+        return rc;
+    }
+    *out = h;
+    return 0;
+}
+
+extern "C" int ldpc_get_dims(const ldpc_handle *h, int *m, int *n, int *edges)
+{
+    if (!h) return fail(LDPC_E_ARG, "handle is NULL");
+    if (m) *m = h->m;
+    if (n) *n = h->n;
+    if (edges) *edges = h->E;
+    return 0;
+}
+
+extern "C" int ldpc_set_stream(ldpc_handle *h, void *hip_stream)
+{
+    if (!h) return fail(LDPC_E_ARG, "handle is NULL");
+    h->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : h->own_stream;
+    return 0;
+}
+
+extern "C" int ldpc_sync(ldpc_handle *h)
+{
+    if (!h) return fail(LDPC_E_ARG, "handle is NULL");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+// ---------------------------------------------------------------- kernel selection
+template <typename T, bool S64, int CPT, int FPW>
+static size_t qc_lds_bytes(const QcTables &tb)
+{
+    const size_t slots = (size_t)FPW * tb.mb * tb.Zp;
+    size_t b = (((size_t)FPW * tb.n * sizeof(T)) + 15) & ~(size_t)15;
+    b += slots * sizeof(typename Vec2<T>::type);
+    b += slots * sizeof(typename SignBits<S64>::Meta);
+    b += 3 * FPW * sizeof(int);
+    return (b + 15) & ~(size_t)15;
+}
+
+template <typename T, bool S64, int CPT, int FPW>
+static int qc_pick(const ldpc_handle *h, Launch *L)
+{
+    L->fn = reinterpret_cast<const void *>(&qc_minsum_kernel<T, S64, CPT, FPW>);
+    L->block = FPW * h->qc.mb * h->qc.Zp;
+    L->fpw = FPW;
+    L->lds = qc_lds_bytes<T, S64, CPT, FPW>(h->qc);
+    return 0;
+}
+
+template <typename T, bool S64>
+static int qc_select(const ldpc_handle *h, Launch *L)
+{
+    const int cpt = h->cols_per_thread;
+    const int thr1 = h->qc.mb * h->qc.Zp;
+    if (cpt <= 8) {
+        // pack several short frames into one workgroup while threads and LDS allow
+        if (thr1 * 4 <= 1024 && qc_lds_bytes<T, S64, 8, 4>(h->qc) <= h->lds_max / 2) return qc_pick<T, S64, 8, 4>(h, L);
+        if (thr1 * 2 <= 1024 && qc_lds_bytes<T, S64, 8, 2>(h->qc) <= h->lds_max / 2) return qc_pick<T, S64, 8, 2>(h, L);
+        return qc_pick<T, S64, 8, 1>(h, L);
+    }
+    if (cpt <= 16) return qc_pick<T, S64, 16, 1>(h, L);
+    return qc_pick<T, S64, 32, 1>(h, L);
+}
+
+static size_t csr_ws_stride(const ldpc_handle *h, int prec)
+{
+    const size_t ts = prec == 64 ? 8 : 4;
+    size_t b = (((size_t)2 * h->n * ts) + 15) & ~(size_t)15;
+    b += (size_t)h->m * 2 * ts;
+    b += (size_t)h->m * 16;
+    return (b + 255) & ~(size_t)255;
+}
+
+static int select_launch(ldpc_handle *h, int algo, int prec, int64_t n_frames, Launch *L)
+{
+    if (algo != LDPC_ALGO_MINSUM)
+        return fail(LDPC_E_UNSUPPORTED, "algorithm %d is not available in this build", algo);
+    if (prec != 32 && prec != 64) return fail(LDPC_E_ARG, "prec must be 32 or 64");
+    HIP_TRY(hipSetDevice(h->device));
+    if (h->is_qc) {
+        const bool s64 = h->max_row_deg > 32;
+        int rc;
+        if (prec == 32) rc = s64 ? qc_select<float, true>(h, L) : qc_select<float, false>(h, L);
+        else            rc = s64 ? qc_select<double, true>(h, L) : qc_select<double, false>(h, L);
+        if (rc) return rc;
+        if (L->lds > h->lds_max)
+            return fail(LDPC_E_UNSUPPORTED, "code needs %zu bytes of LDS per workgroup, device has %zu", L->lds, h->lds_max);
+        HIP_TRY(hipFuncSetAttribute(L->fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L->lds));
+        int per_cu = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, L->fn, L->block, L->lds));
+        if (per_cu < 1) per_cu = 1;
+        const int64_t fblocks = (n_frames + L->fpw - 1) / L->fpw;
+        L->grid = (int)std::max<int64_t>(1, std::min<int64_t>(fblocks, (int64_t)h->n_cu * per_cu));
+    } else {
+        L->fn = prec == 32 ? reinterpret_cast<const void *>(&csr_minsum_kernel<float>)
+                           : reinterpret_cast<const void *>(&csr_minsum_kernel<double>);
+        L->block = 256;
+        L->fpw = 1;
+        L->lds = 0;
+        L->grid = (int)std::max<int64_t>(1, std::min<int64_t>(n_frames, (int64_t)h->n_cu * 4));
+    }
+    return 0;
+}
+
+static int launch_decode(ldpc_handle *h, int algo, int prec, const DecodeArgs &args)
+{
+    Launch L;
+    int rc = select_launch(h, algo, prec, args.n_frames, &L);
+    if (rc) return rc;
+    if (h->is_qc) {
+        QcTables tb = h->qc;
+        DecodeArgs a = args;
+        void *kargs[] = {&tb, &a};
+        HIP_TRY(hipLaunchKernel(L.fn, dim3(L.grid), dim3(L.block), kargs, L.lds, h->stream));
+    } else {
+        size_t stride = csr_ws_stride(h, prec);
+        if ((rc = h->b_ws.ensure(stride * (size_t)L.grid))) return rc;
+        CsrTables tb = h->csr;
+        DecodeArgs a = args;
+        unsigned char *ws = reinterpret_cast<unsigned char *>(h->b_ws.p);
+        void *kargs[] = {&tb, &a, &ws, &stride};
+        HIP_TRY(hipLaunchKernel(L.fn, dim3(L.grid), dim3(L.block), kargs, 0, h->stream));
+    }
+    return 0;
+}
+
+static int check_common(ldpc_handle *h, int max_iters, int64_t n_frames, int sign_mode)
+{
+    if (!h) return fail(LDPC_E_ARG, "handle is NULL");
+    if (max_iters < 0) return fail(LDPC_E_ARG, "max_iters must be >= 0");
+    if (n_frames < 0) return fail(LDPC_E_ARG, "n_frames must be >= 0");
+    if (sign_mode != LDPC_SIGN_REFERENCE && sign_mode != LDPC_SIGN_CORRECTED)
+        return fail(LDPC_E_ARG, "sign_mode must be 0 or 1");
+    return 0;
+}
+
+extern "C" int ldpc_get_launch_info(ldpc_handle *h, int algo, int prec, int *grid, int *block,
+                                    int *lds_bytes, int *frames_per_wg)
+{
+    if (!h) return fail(LDPC_E_ARG, "handle is NULL");
+    Launch L;
+    int rc = select_launch(h, algo, prec, INT64_MAX / 2, &L);
+    if (rc) return rc;
+    if (grid) *grid = L.grid;
+    if (block) *block = L.block;
+    if (lds_bytes) *lds_bytes = (int)L.lds;
+    if (frames_per_wg) *frames_per_wg = L.fpw;
+    return 0;
+}
+
+extern "C" int ldpc_decode_device(ldpc_handle *h, int algo, int prec, int sign_mode, int max_iters,
+                                  int64_t n_frames, const void *d_llr, int llr_bits, float llr_scale,
+                                  uint8_t *d_hard_bits, int32_t *d_iters, uint8_t *d_converged,
+                                  int32_t *d_ones, void *d_soft_out)
+{
+    int rc = check_common(h, max_iters, n_frames, sign_mode);
+    if (rc) return rc;
+    if (n_frames == 0) return 0;
+    if (!d_llr) return fail(LDPC_E_ARG, "d_llr is NULL");
+    if (llr_bits != 32 && llr_bits != 64) return fail(LDPC_E_ARG, "llr_bits must be 32 or 64");
+    DecodeArgs a;
+    a.llr = d_llr; a.llr_f64 = llr_bits == 64; a.llr_scale = llr_scale; a.n_frames = n_frames; a.max_iters = max_iters;
+    a.sign_mode = sign_mode; a.hard = d_hard_bits; a.iters = d_iters; a.conv = d_converged;
+    a.ones = d_ones; a.soft = d_soft_out;
+    return launch_decode(h, algo, prec, a);
+}
+
+extern "C" int ldpc_decode(ldpc_handle *h, int algo, int prec, int sign_mode, int max_iters,
+                           int64_t n_frames, const void *llr, int llr_bits, uint8_t *hard_bits,
+                           int32_t *iters, uint8_t *converged, int32_t *ones, void *soft_out)
+{
+    int rc = check_common(h, max_iters, n_frames, sign_mode);
+    if (rc) return rc;
+    if (n_frames == 0) return 0;
+    if (!llr) return fail(LDPC_E_ARG, "llr is NULL");
+    if (prec != 32 && prec != 64) return fail(LDPC_E_ARG, "prec must be 32 or 64");
+    if (llr_bits != 32 && llr_bits != 64) return fail(LDPC_E_ARG, "llr_bits must be 32 or 64");
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t n = (size_t)h->n, nbytes = (n + 7) / 8, ts = prec == 64 ? 8 : 4, ls = llr_bits / 8;
+    // stage at most ~256 MB of channel values at a time
+    const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(n_frames, (int64_t)((256u << 20) / (n * ls)) + 1));
+    if ((rc = h->b_llr.ensure((size_t)chunk * n * ls)) || (rc = h->b_hard.ensure((size_t)chunk * nbytes)) ||
+        (rc = h->b_iters.ensure((size_t)chunk * 4)) || (rc = h->b_conv.ensure((size_t)chunk)) ||
+        (rc = h->b_ones.ensure((size_t)chunk * 4)))
+        return rc;
+    if (soft_out && (rc = h->b_soft.ensure((size_t)chunk * n * ts))) return rc;
+    for (int64_t f0 = 0; f0 < n_frames; f0 += chunk) {
+        const int64_t nf = std::min<int64_t>(chunk, n_frames - f0);
+        HIP_TRY(hipMemcpyAsync(h->b_llr.p, reinterpret_cast<const unsigned char *>(llr) + (size_t)f0 * n * ls,
+                               (size_t)nf * n * ls, hipMemcpyHostToDevice, h->stream));
+        DecodeArgs a;
+        a.llr = h->b_llr.p; a.llr_f64 = llr_bits == 64; a.llr_scale = 1.0f; a.n_frames = nf;
+        a.max_iters = max_iters; a.sign_mode = sign_mode;
+        a.hard = reinterpret_cast<uint8_t *>(h->b_hard.p);
+        a.iters = reinterpret_cast<int32_t *>(h->b_iters.p);
+        a.conv = reinterpret_cast<uint8_t *>(h->b_conv.p);
+        a.ones = reinterpret_cast<int32_t *>(h->b_ones.p);
+        a.soft = soft_out ? h->b_soft.p : nullptr;
+        if ((rc = launch_decode(h, algo, prec, a))) return rc;
+        if (hard_bits) HIP_TRY(hipMemcpyAsync(hard_bits + (size_t)f0 * nbytes, h->b_hard.p, (size_t)nf * nbytes, hipMemcpyDeviceToHost, h->stream));
+        if (iters) HIP_TRY(hipMemcpyAsync(iters + f0, h->b_iters.p, (size_t)nf * 4, hipMemcpyDeviceToHost, h->stream));
+        if (converged) HIP_TRY(hipMemcpyAsync(converged + f0, h->b_conv.p, (size_t)nf, hipMemcpyDeviceToHost, h->stream));
+        if (ones) HIP_TRY(hipMemcpyAsync(ones + f0, h->b_ones.p, (size_t)nf * 4, hipMemcpyDeviceToHost, h->stream));
+        if (soft_out) HIP_TRY(hipMemcpyAsync(reinterpret_cast<unsigned char *>(soft_out) + (size_t)f0 * n * ts, h->b_soft.p, (size_t)nf * n * ts, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    return 0;
+}
+
+static int launch_channel(ldpc_handle *h, double snr_db, uint64_t seed, uint32_t stream_id,
+                          uint64_t first_frame, int64_t n_frames, float *d_llr, float *d_sigma_hat,
+                          int32_t *d_uncoded)
+{
+    const double snr = pow(10.0, snr_db / 10.0);         // ldpc.py:53
+    const float sigma = (float)sqrt(0.5 / snr);          // ldpc.py:55
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(n_frames, (int64_t)h->n_cu * 8));
+    hipLaunchKernelGGL(channel_awgn_kernel, dim3(grid), dim3(256), 0, h->stream, seed, stream_id,
+                       first_frame, n_frames, h->n, sigma, d_llr, d_sigma_hat, d_uncoded);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int ldpc_channel_awgn_device(ldpc_handle *h, double snr_db, uint64_t seed, uint64_t first_frame,
+                                        int64_t n_frames, float *d_llr, float *d_sigma_hat,
+                                        int32_t *d_uncoded)
+{
+    if (!h) return fail(LDPC_E_ARG, "handle is NULL");
+    if (n_frames < 0) return fail(LDPC_E_ARG, "n_frames must be >= 0");
+    if (n_frames == 0) return 0;
+    if (!d_llr) return fail(LDPC_E_ARG, "d_llr is NULL");
+    HIP_TRY(hipSetDevice(h->device));
+    return launch_channel(h, snr_db, seed, 0u, first_frame, n_frames, d_llr, d_sigma_hat, d_uncoded);
+}
+
+extern "C" int ldpc_eval_awgn(ldpc_handle *h, int algo, int prec, int sign_mode, int max_iters,
+                              int n_snr, const double *snr_db, int64_t frames_per_snr,
+                              uint64_t seed, uint64_t first_frame, uint64_t *counters,
+                              float *per_frame)
+{
+    int rc = check_common(h, max_iters, frames_per_snr, sign_mode);
+    if (rc) return rc;
+    if (n_snr < 0 || (n_snr > 0 && !snr_db)) return fail(LDPC_E_ARG, "bad SNR list");
+    if (!counters) return fail(LDPC_E_ARG, "counters is NULL");
+    memset(counters, 0, sizeof(uint64_t) * 6 * (size_t)n_snr);
+    if (n_snr == 0 || frames_per_snr == 0) return 0;
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t n = (size_t)h->n;
+    const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(frames_per_snr, (int64_t)((1024u << 20) / (n * 4)) + 1));
+    if ((rc = h->b_llr.ensure((size_t)chunk * n * 4)) || (rc = h->b_iters.ensure((size_t)chunk * 4)) ||
+        (rc = h->b_conv.ensure((size_t)chunk)) || (rc = h->b_ones.ensure((size_t)chunk * 4)) ||
+        (rc = h->b_sig.ensure((size_t)chunk * 4)) || (rc = h->b_unc.ensure((size_t)chunk * 4)) ||
+        (rc = h->b_cnt.ensure(sizeof(uint64_t) * 6 * (size_t)n_snr)))
+        return rc;
+    if (per_frame && (rc = h->b_pf.ensure((size_t)chunk * 16))) return rc;
+    HIP_TRY(hipMemsetAsync(h->b_cnt.p, 0, sizeof(uint64_t) * 6 * (size_t)n_snr, h->stream));
+    for (int s = 0; s < n_snr; ++s) {
+        for (int64_t f0 = 0; f0 < frames_per_snr; f0 += chunk) {
+            const int64_t nf = std::min<int64_t>(chunk, frames_per_snr - f0);
+            if ((rc = launch_channel(h, snr_db[s], seed, (uint32_t)s, first_frame + (uint64_t)f0, nf,
+                                     reinterpret_cast<float *>(h->b_llr.p),
+                                     reinterpret_cast<float *>(h->b_sig.p),
+                                     reinterpret_cast<int32_t *>(h->b_unc.p))))
+                return rc;
+            DecodeArgs a;
+            a.llr = h->b_llr.p; a.llr_f64 = 0; a.llr_scale = 1.0f; a.n_frames = nf;
+            a.max_iters = max_iters; a.sign_mode = sign_mode; a.hard = nullptr;
+            a.iters = reinterpret_cast<int32_t *>(h->b_iters.p);
+            a.conv = reinterpret_cast<uint8_t *>(h->b_conv.p);
+            a.ones = reinterpret_cast<int32_t *>(h->b_ones.p);
+            a.soft = nullptr;
+            if ((rc = launch_decode(h, algo, prec, a))) return rc;
+            const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((nf + 255) / 256, 1024));
+            hipLaunchKernelGGL(accumulate_kernel, dim3(grid), dim3(256), 0, h->stream, nf,
+                               reinterpret_cast<const int32_t *>(h->b_iters.p),
+                               reinterpret_cast<const uint8_t *>(h->b_conv.p),
+                               reinterpret_cast<const int32_t *>(h->b_ones.p),
+                               reinterpret_cast<const int32_t *>(h->b_unc.p),
+                               reinterpret_cast<const float *>(h->b_sig.p),
+                               reinterpret_cast<unsigned long long *>(h->b_cnt.p) + 6 * s,
+                               per_frame ? reinterpret_cast<float *>(h->b_pf.p) : nullptr);
+            HIP_TRY(hipGetLastError());
+            if (per_frame)
+                HIP_TRY(hipMemcpyAsync(per_frame + ((size_t)s * frames_per_snr + f0) * 4, h->b_pf.p,
+                                       (size_t)nf * 16, hipMemcpyDeviceToHost, h->stream));
+        }
+    }
+    HIP_TRY(hipMemcpyAsync(counters, h->b_cnt.p, sizeof(uint64_t) * 6 * (size_t)n_snr, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return 0;
+}

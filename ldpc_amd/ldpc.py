@@ -1,0 +1,280 @@
+"""Mirror of the Python entry points of the reference's ``ldpc.py`` on top of
+the HIP engine.  Same names, argument order, return values and assertion
+behaviour; the arithmetic of every decode is done on the GPU by libldpc_hip.so
+in float64 (the reference's LDPC_DECIMAL_DATA_TYPE, ldpc.py:29), which makes
+hard decisions, soft outputs and iteration counts bit-identical to the
+reference's for a freshly constructed decoder.
+
+Deliberate differences (each is also noted where it occurs):
+  * a decoder object does not carry check-node messages from one
+    decoderMainLoop call to the next (the reference's decoderSet only resets
+    variable nodes, ldpc.py:270-274); every call behaves like the first call
+    on a new reference decoder;
+  * testCodeUsingMultiprocessing runs all transmissions of an SNR point as one
+    GPU batch instead of a 2-process pool (ldpc.py:454-458).
+"""
+import copy
+import hashlib
+import os
+import time
+
+import numpy as np
+
+from . import codes, common
+from .engine import Decoder
+
+projectDir = os.environ.get('SWIFT')          # ldpc.py:11
+LDPC_LOCAL_PRNG = np.random.RandomState(7134066)   # ldpc.py:24
+LDPC_DATA_TYPE = np.int64
+LDPC_INT_DATA_TYPE = np.int64
+LDPC_DECIMAL_DATA_TYPE = np.float64
+LDPC_SEED_DATA_TYPE = np.int64
+LDPC_MAX_SEED = 2 ** 31 - 1
+LDPC_HIP_DEVICE = int(os.environ.get('LDPC_HIP_DEVICE', '0'))
+
+
+def slicer(vector, length):
+    """Hard decision: 1 where vector > 0, else 0 (ldpc.py:43-48)."""
+    out = np.ones(length, dtype=LDPC_INT_DATA_TYPE)
+    out[np.where(np.asarray(vector) <= 0)] = 0
+    return out
+
+
+def addAWGN(vector, length, SNRdb, prng):
+    """vector + N(0, sigma), sigma = sqrt(0.5 / 10^(SNRdb/10)); returns
+    (noisy, sigma, sigmaActual) (ldpc.py:51-60)."""
+    SNR = 10 ** (SNRdb / 10)
+    sigma = np.sqrt(0.5 / SNR)
+    noise = prng.normal(0, sigma, length)
+    sigmaActual = np.sqrt((np.sum(noise ** 2)) / length)
+    return vector + noise, sigma, sigmaActual
+
+
+def modulate(vector, length):
+    """BPSK: 0 -> -1, anything else -> +1 (ldpc.py:62-66)."""
+    out = np.ones(length, dtype=LDPC_DECIMAL_DATA_TYPE)
+    out[np.where(np.asarray(vector) == 0)] = -1
+    return out
+
+
+# ------------------------------------------------------------------ decoder cache
+_DECODERS = {}
+_DECODERS_MAX = 8
+
+
+def _engine_for(H, device=None):
+    """HIP decoder for H (dense array or codes.QCCode).  The gym hands over a new
+    dense matrix at every step (ldpc_env.py:313, 370), so engines are cached by
+    content and the least recently used one is dropped."""
+    device = LDPC_HIP_DEVICE if device is None else device
+    if isinstance(H, codes.QCCode):
+        key = (device,) + H.key()
+    else:
+        Ha = np.ascontiguousarray(np.asarray(H) != 0)
+        key = (device, Ha.shape, hashlib.sha1(np.packbits(Ha).tobytes()).hexdigest())
+    eng = _DECODERS.pop(key, None)
+    if eng is None:
+        eng = Decoder(H, device=device)
+        while len(_DECODERS) >= _DECODERS_MAX:
+            _DECODERS.pop(next(iter(_DECODERS))).close()
+    _DECODERS[key] = eng
+    return eng
+
+
+class ldpcDecoder:
+    """Mirror of ldpc.ldpcDecoder (ldpc.py:223-337)."""
+
+    def __init__(self, H, device=None):
+        self.parityMatrix = H
+        if isinstance(H, codes.QCCode):
+            m, n = H.m, H.n
+        else:
+            m, n = np.asarray(H).shape
+        self.numberOfVariableNodes = n
+        self.numberOfCheckNodes = m
+        self.codewordLength = n
+        self.softVector = np.zeros(n, dtype=LDPC_DECIMAL_DATA_TYPE)
+        self._engine = _engine_for(H, device)
+
+    def isCodeword(self, modulatedVector):
+        """('Codeword' | 'Not a codeword', hard decision int64[n]) (ldpc.py:249-268).
+        Evaluated by the decode kernel with an iteration budget of 0."""
+        r = self._engine.decode(np.asarray(modulatedVector, dtype=LDPC_DECIMAL_DATA_TYPE), 0, prec=64)
+        status = 'Codeword' if r['converged'][0] else 'Not a codeword'
+        return status, r['hard'][0].astype(LDPC_INT_DATA_TYPE)
+
+    def decoderMainLoop(self, fromChannel, maxNumberOfIterations):
+        """-> (status, binaryVector int64[n], softVector float64[n], iterations) (ldpc.py:326-337)"""
+        y = np.asarray(fromChannel, dtype=LDPC_DECIMAL_DATA_TYPE)
+        r = self._engine.decode(y, maxNumberOfIterations, prec=64, want_soft=True)
+        it = int(r['iters'][0])
+        status = 'Codeword' if r['converged'][0] else 'Not a codeword'
+        # zero iterations: the reference returns a copy of its input (ldpc.py:328)
+        soft = np.copy(y) if it == 0 else r['soft'][0]
+        self.softVector = soft
+        return status, r['hard'][0].astype(LDPC_INT_DATA_TYPE), soft, it
+
+    def decodeBatch(self, fromChannel, maxNumberOfIterations, wantSoft=False):
+        """Many frames at once ([F, n]); not in the reference.  -> engine result dict."""
+        return self._engine.decode(np.asarray(fromChannel, dtype=LDPC_DECIMAL_DATA_TYPE),
+                                   maxNumberOfIterations, prec=64, want_soft=wantSoft)
+
+
+def testModulationAndSlicingRoundTrip():
+    vectorLength = 100
+    v = np.random.randint(0, 1, vectorLength, dtype=LDPC_DATA_TYPE)
+    assert np.all(v == slicer(modulate(v, vectorLength), vectorLength))
+    return 'OK'
+
+
+def _status(flag):
+    return 'Codeword' if flag else 'Not a codeword'
+
+
+def evaluateCode(numberOfTransmissions, seed, SNRpoints, messageSize, codewordSize, numberOfIterations, H,
+                 G='None'):
+    """SNR x transmissions sweep of the all-zero codeword (ldpc.py:350-388).
+
+    As in the reference the noise comes from the module-global LDPC_LOCAL_PRNG
+    (the seed argument only has to be positive, ldpc.py:353-355, 372), in
+    float64, and berUncoded is reported as 0 (ldpc.py:374).  All frames are
+    drawn first, in the reference's order, and decoded as one GPU batch."""
+    assert (seed > 0)
+    assert hasattr(SNRpoints, "__len__")
+    decoder = ldpcDecoder(H)
+    berStats = common.berStatistics()
+    codeword = np.zeros(codewordSize, dtype=LDPC_INT_DATA_TYPE)
+    modulatedCodeword = modulate(codeword, codewordSize)
+    frames, meta = [], []
+    for SNR in SNRpoints:
+        for _ in range(numberOfTransmissions):
+            dirty, sigma, sigmaActual = addAWGN(modulatedCodeword, codewordSize, SNR, LDPC_LOCAL_PRNG)
+            frames.append(dirty)
+            meta.append((SNR, sigma, sigmaActual))
+    if frames:
+        start = time.time()
+        r = decoder.decodeBatch(np.stack(frames), numberOfIterations)
+        timeTotal = time.time() - start
+        for k, (SNR, sigma, sigmaActual) in enumerate(meta):
+            berDecoded = int(np.count_nonzero(r['hard'][k] != codeword))
+            berStats.addEntry(SNR, sigma, sigmaActual, 0, berDecoded, int(r['iters'][k]),
+                              numberOfIterations, _status(r['converged'][k]))
+        print("Time it took the decoder:")
+        print(timeTotal)
+        print("And the throughput is:")
+        print(len(frames) * codewordSize / max(timeTotal, 1e-12))
+    return berStats
+
+
+def _single_transmission_frames(localPrng, SNRpoints, messageSize, codewordSize, G):
+    """Frames of evaluateCodeAtSingleTransmission (ldpc.py:402-422): the AWGN sample
+    is drawn (it advances LDPC_LOCAL_PRNG and supplies sigmaActual) but the frame
+    that is decoded is the clean codeword with its first symbol negated
+    (ldpc.py:416-418)."""
+    frames, meta = [], []
+    for SNR in SNRpoints:
+        if isinstance(G, str) and G == 'None':
+            codeword = np.zeros(codewordSize, dtype=LDPC_INT_DATA_TYPE)
+        else:
+            message = localPrng.randint(0, 2, messageSize, dtype=LDPC_INT_DATA_TYPE)
+            codeword = G.dot(message) % 2
+        modulatedCodeword = modulate(codeword, codewordSize)
+        _, sigma, sigmaActual = addAWGN(modulatedCodeword, codewordSize, SNR, LDPC_LOCAL_PRNG)
+        dirty = copy.copy(modulatedCodeword)
+        dirty[0] = dirty[0] * -1
+        berUncoded = int(np.count_nonzero(slicer(dirty, codewordSize) != codeword))
+        frames.append(dirty)
+        meta.append((SNR, sigma, sigmaActual, berUncoded, codeword))
+    return frames, meta
+
+
+def evaluateCodeAtSingleTransmission(seed, SNRpoints, messageSize, codewordSize, numberOfIterations, H,
+                                     G='None'):
+    """One frame per SNR point (ldpc.py:391-430)."""
+    assert (seed > 0)
+    assert hasattr(SNRpoints, "__len__")
+    localPrng = np.random.RandomState(seed)
+    decoder = ldpcDecoder(H)
+    berStats = common.berStatistics()
+    frames, meta = _single_transmission_frames(localPrng, SNRpoints, messageSize, codewordSize, G)
+    if frames:
+        r = decoder.decodeBatch(np.stack(frames), numberOfIterations)
+        for k, (SNR, sigma, sigmaActual, berUncoded, codeword) in enumerate(meta):
+            berDecoded = int(np.count_nonzero(r['hard'][k] != codeword))
+            berStats.addEntry(SNR, sigma, sigmaActual, berUncoded, berDecoded, int(r['iters'][k]),
+                              numberOfIterations, _status(r['converged'][k]))
+    return berStats
+
+
+def constantFunction(const):
+    def g(x):
+        return const
+    return g
+
+
+def testCodeUsingMultiprocessing(seed, SNRpoints, messageSize, codewordSize, numberOfIterations,
+                                 numberOfTransmissions, H, method=None, reference=None, G='None'):
+    """numberOfTransmissions single-transmission evaluations per SNR point, merged
+    with berStatistics.union (ldpc.py:438-476).  The reference maps them over a
+    process pool; here they form one GPU batch per SNR point.  With `method`
+    set the sweep stops at the first point whose BER at the lowest evaluated SNR
+    exceeds `reference` (ldpc.py:465-475)."""
+    bStats = common.berStatistics()
+    seeds = LDPC_LOCAL_PRNG.randint(0, LDPC_MAX_SEED, numberOfTransmissions, dtype=LDPC_SEED_DATA_TYPE)
+    decoder = ldpcDecoder(H)
+    for s in SNRpoints:
+        start = time.time()
+        frames, meta = [], []
+        for sd in seeds:
+            assert (sd > 0)
+            f, mt = _single_transmission_frames(np.random.RandomState(sd), [s], messageSize, codewordSize, G)
+            frames += f
+            meta += mt
+        if frames:
+            r = decoder.decodeBatch(np.stack(frames), numberOfIterations)
+            for k, (SNR, sigma, sigmaActual, berUncoded, codeword) in enumerate(meta):
+                one = common.berStatistics()
+                one.addEntry(SNR, sigma, sigmaActual, berUncoded,
+                             int(np.count_nonzero(r['hard'][k] != codeword)), int(r['iters'][k]),
+                             numberOfIterations, _status(r['converged'][k]))
+                bStats = bStats.union(one)
+        if method is None:
+            end = time.time()
+            print(" Time it took the decoder at snr " + str(s) + " is:")
+            print(end - start)
+            print("And the throughput is: ")
+            print(numberOfTransmissions * codewordSize / max(end - start, 1e-12))
+        else:
+            snrAxis, averageSnrAxis, berData, averageNumberOfIterations = bStats.getStats(messageSize)
+            print(berData)
+            if berData[0] > reference:
+                print("*** Evaluation failed at " + str(len(bStats.snrAxis)))
+                break
+    return bStats
+
+
+def testNearEarth(numOfTransmissions=50):
+    """ldpc.py:480-501: NearEarth, SNR 3.0..3.6 dB, 50 iterations, seed 460101."""
+    print("*** in test near earth")
+    nearEarthParity = codes.near_earth()
+    roi = [3.0, 3.2, 3.4, 3.6]
+    codewordSize = 8176
+    messageSize = 7154
+    numOfIterations = 50
+    start = time.time()
+    bStats = testCodeUsingMultiprocessing(460101, roi, messageSize, codewordSize, numOfIterations,
+                                          numOfTransmissions, nearEarthParity)
+    end = time.time()
+    print('****Time it took for code evaluation == %d' % (end - start))
+    print('****Throughput == ' + str((8176 * len(roi) * numOfTransmissions) / max(end - start, 1e-12))
+          + 'bits per second.')
+    return bStats
+
+
+def main():
+    print("*** In ldpc.py main function.")
+    return testNearEarth()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,145 @@
+/*
+ * TEST INFRASTRUCTURE -- not product code.
+ *
+ * CPU restatement ("oracle") of the reference's LDPC decode path, used only by
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg as the
+ * checker / timed CPU baseline.  The shipped library never links or calls it.
+ *
+ * Follows /root/reference/ldpc.py:43-66 (slicer, addAWGN, modulate),
+ * :135-202 (check node), :249-337 (decoder loop) and nothing else.  Pinned by
+ * tests/golden/ (outputs of the reference's own source executed in the build
+ * container, see oracle/gen_golden.py).
+ *
+ * Build: make -C oracle   (gcc -O2 -ffp-contract=off -fopenmp)
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+typedef struct oracle_graph {
+    int m, n, E;
+    int32_t *row_ptr;   /* [m+1]                                              */
+    int32_t *col_idx;   /* [E] columns of each row, ascending (ldpc.py:244)   */
+    int32_t *col_ptr;   /* [n+1]                                              */
+    int32_t *col_edge;  /* [E] edge ids of each column, ascending row
+                           (= order in which checks update a variable,
+                           ldpc.py:298-303)                                    */
+} oracle_graph;
+
+/* Graph from CSR (what ldpcDecoder.__init__ derives from dense H, ldpc.py:225-247). */
+oracle_graph *oracle_graph_create(int m, int n, const int32_t *row_ptr, const int32_t *col_idx)
+{
+    oracle_graph *g = (oracle_graph *)calloc(1, sizeof(*g));
+    if (!g) return NULL;
+    g->m = m; g->n = n; g->E = row_ptr[m];
+    g->row_ptr = (int32_t *)malloc(sizeof(int32_t) * (size_t)(m + 1));
+    g->col_idx = (int32_t *)malloc(sizeof(int32_t) * (size_t)(g->E > 0 ? g->E : 1));
+    g->col_ptr = (int32_t *)calloc((size_t)(n + 1), sizeof(int32_t));
+    g->col_edge = (int32_t *)malloc(sizeof(int32_t) * (size_t)(g->E > 0 ? g->E : 1));
+    memcpy(g->row_ptr, row_ptr, sizeof(int32_t) * (size_t)(m + 1));
+    memcpy(g->col_idx, col_idx, sizeof(int32_t) * (size_t)g->E);
+    for (int e = 0; e < g->E; ++e) g->col_ptr[col_idx[e] + 1]++;
+    for (int c = 0; c < n; ++c) g->col_ptr[c + 1] += g->col_ptr[c];
+    int32_t *fill = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));
+    memcpy(fill, g->col_ptr, sizeof(int32_t) * (size_t)n);
+    for (int r = 0; r < m; ++r)                 /* rows ascending => per-column ascending row */
+        for (int e = row_ptr[r]; e < row_ptr[r + 1]; ++e)
+            g->col_edge[fill[col_idx[e]]++] = e;
+    free(fill);
+    return g;
+}
+
+void oracle_graph_destroy(oracle_graph *g)
+{
+    if (!g) return;
+    free(g->row_ptr); free(g->col_idx); free(g->col_ptr); free(g->col_edge); free(g);
+}
+
+int oracle_graph_edges(const oracle_graph *g) { return g->E; }
+
+#define CAT_(a, b) a##b
+#define CAT(a, b) CAT_(a, b)
+
+/* isCodeword (ldpc.py:249-268): H . (x > 0) mod 2 == 0 */
+#define SYNDROME_BODY                                                         \
+    for (int r = 0; r < g->m; ++r) {                                          \
+        int p = 0;                                                            \
+        for (int e = g->row_ptr[r]; e < g->row_ptr[r + 1]; ++e)               \
+            p ^= (x[g->col_idx[e]] > 0);                                      \
+        if (p) return 0;                                                      \
+    }                                                                         \
+    return 1;
+
+static int f64_syndrome_is_zero(const oracle_graph *g, const double *x) { SYNDROME_BODY }
+static int f32_syndrome_is_zero(const oracle_graph *g, const float *x) { SYNDROME_BODY }
+
+#define REAL double
+#define FABS fabs
+#define FN(name) CAT(f64_, name)
+#include "minsum_impl.h"
+#undef REAL
+#undef FABS
+#undef FN
+
+#define REAL float
+#define FABS fabsf
+#define FN(name) CAT(f32_, name)
+#include "minsum_impl.h"
+#undef REAL
+#undef FABS
+#undef FN
+
+/* Batch drivers.  y: [frames][n]; hard: [frames][n] bytes 0/1 or NULL;
+ * iters: [frames]; conv: [frames]; soft: [frames][n] or NULL.
+ * threads <= 0 -> 1 thread.  Returns 0, or -1 on allocation failure. */
+#define BATCH_BODY(REAL_T, PFX)                                               \
+    int fail = 0;                                                             \
+    if (threads <= 0) threads = 1;                                            \
+    _Pragma("omp parallel num_threads(threads)")                              \
+    {                                                                         \
+        REAL_T *c2v = (REAL_T *)malloc(sizeof(REAL_T) * (size_t)(g->E + 1));  \
+        REAL_T *v2c = (REAL_T *)malloc(sizeof(REAL_T) * (size_t)(g->E + 1));  \
+        REAL_T *post = (REAL_T *)malloc(sizeof(REAL_T) * (size_t)(g->n + 1)); \
+        if (!c2v || !v2c || !post) {                                          \
+            _Pragma("omp atomic write")                                       \
+            fail = 1;                                                         \
+        } else {                                                              \
+            _Pragma("omp for schedule(dynamic, 1)")                           \
+            for (int64_t f = 0; f < n_frames; ++f)                            \
+                PFX##decode_frame(g, sign_mode, max_iters,                    \
+                                  y + (size_t)f * g->n,                       \
+                                  hard ? hard + (size_t)f * g->n : NULL,      \
+                                  iters + f, conv + f,                        \
+                                  soft ? soft + (size_t)f * g->n : NULL,      \
+                                  c2v, v2c, post);                            \
+        }                                                                     \
+        free(c2v); free(v2c); free(post);                                     \
+    }                                                                         \
+    return fail ? -1 : 0;
+
+int oracle_minsum_f64(const oracle_graph *g, int sign_mode, int max_iters, int64_t n_frames,
+                      const double *y, uint8_t *hard, int32_t *iters, uint8_t *conv,
+                      double *soft, int threads)
+{
+    BATCH_BODY(double, f64_)
+}
+
+int oracle_minsum_f32(const oracle_graph *g, int sign_mode, int max_iters, int64_t n_frames,
+                      const float *y, uint8_t *hard, int32_t *iters, uint8_t *conv,
+                      float *soft, int threads)
+{
+    BATCH_BODY(float, f32_)
+}
+
+int oracle_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

@@ -1,0 +1,78 @@
+"""CPU suite: the oracle (C restatement of ldpc.py's decoder) against the golden
+vectors produced by the reference's own source (tests/golden, oracle/gen_golden.py)."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from conftest import ALL_CODES, build_code, golden_points
+
+
+@pytest.mark.parametrize('name', ALL_CODES)
+def test_oracle_f64_matches_reference_bit_for_bit(oracle_mod, name):
+    _, H = build_code(name)
+    orc = oracle_mod.Oracle(H)
+    n_frames = 0
+    for pt in golden_points(name):
+        hard, iters, conv, soft = orc.minsum(pt['llr'].astype(np.float64), pt['max_iters'], prec=64, threads=8)
+        assert np.array_equal(iters, pt['iters']), (name, pt['seed'])
+        assert np.array_equal(conv, pt['conv'])
+        assert np.array_equal(np.packbits(hard, axis=1, bitorder='little'), pt['hard'])
+        for k in range(len(iters)):
+            assert hashlib.sha256(soft[k].tobytes()).digest() == bytes(pt['sha'][k]), (name, pt['seed'], k)
+            assert np.array_equal(soft[k, :8], pt['head'][k])
+        n_frames += len(iters)
+    assert n_frames > 0
+
+
+def test_numpy_restatement_agrees_with_c_oracle(oracle_mod):
+    _, H = build_code('rand_24_48')
+    orc = oracle_mod.Oracle(H)
+    for pt in golden_points('rand_24_48'):
+        Y = pt['llr'][:8]
+        for dtype, prec in ((np.float64, 64), (np.float32, 32)):
+            hard, iters, conv, soft = orc.minsum(Y.astype(dtype), 50, prec=prec)
+            for k in range(len(Y)):
+                h2, it2, ok2, s2 = oracle_mod.minsum_numpy(H, Y[k], 50, dtype=dtype)
+                assert it2 == iters[k] and bool(ok2) == bool(conv[k])
+                assert np.array_equal(h2, hard[k])
+                assert np.array_equal(s2, soft[k])
+
+
+def test_numpy_restatement_on_one_wifi_frame(oracle_mod):
+    _, H = build_code('wifi_5_6')
+    pts = list(golden_points('wifi_5_6'))
+    pt = [p for p in pts if p['snr'] == 8.0][0]
+    k = int(np.argmax(pt['iters']))
+    h2, it2, ok2, s2 = oracle_mod.minsum_numpy(H, pt['llr'][k].astype(np.float64), 50)
+    assert it2 == pt['iters'][k] and bool(ok2) == bool(pt['conv'][k])
+    assert hashlib.sha256(np.ascontiguousarray(s2).tobytes()).digest() == bytes(pt['sha'][k])
+
+
+def test_oracle_f32_is_deterministic_and_close_to_f64(oracle_mod):
+    _, H = build_code('nearEarth')
+    orc = oracle_mod.Oracle(H)
+    pt = [p for p in golden_points('nearEarth') if p['snr'] == 4.5 and not p['special']][0]
+    h32, it32, c32, s32 = orc.minsum(pt['llr'], 50, prec=32, threads=8)
+    h32b, it32b, _, s32b = orc.minsum(pt['llr'], 50, prec=32, threads=3)
+    assert np.array_equal(s32, s32b) and np.array_equal(it32, it32b)
+    # converged frames at high SNR: float32 and float64 arithmetic agree on decisions
+    assert np.array_equal(np.packbits(h32, axis=1, bitorder='little'), pt['hard'])
+    assert np.array_equal(it32, pt['iters'])
+
+
+def test_oracle_edge_cases(oracle_mod):
+    _, H = build_code('rand_24_48')
+    orc = oracle_mod.Oracle(H)
+    n = H.shape[1]
+    # zero iteration budget: status of the channel hard decision, no update
+    y = np.full((1, n), -1.0)
+    y[0, 3] = 0.5
+    hard, iters, conv, soft = orc.minsum(y, 0, prec=64)
+    assert iters[0] == 0 and conv[0] == 0 and np.array_equal(soft[0], y[0]) and hard[0, 3] == 1
+    # exact zeros decide 0 (x > 0 is False): all-zero input is a codeword after 0 iterations
+    hard, iters, conv, soft = orc.minsum(np.zeros((1, n)), 50, prec=64)
+    assert iters[0] == 0 and conv[0] == 1 and hard.sum() == 0
+    # empty batch
+    hard, iters, conv, soft = orc.minsum(np.zeros((0, n)), 50, prec=64)
+    assert hard.shape == (0, n) and iters.shape == (0,)
