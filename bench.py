@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""Headline benchmark: decoded info Gbit/s, NearEarth (8176,7154) min-sum, <= 50 iterations,
+early stop on zero syndrome, BPSK/AWGN 3.5 dB (sigma = sqrt(0.5/10^(dB/10)), the reference's
+SNR definition, ldpc.py:53-55), 10^6 frames per GPU resident in HBM.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One step = one pass of the decode path over the rank's batch of frames (one kernel launch
+of qc_minsum_kernel) followed by the reduction of the error counters over ranks (RCCL
+all-reduce of 6 uint64 when N > 1).  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+K_INFO = 7154          # message size the metric is quoted on (ldpc.py:486, BASELINE.json)
+N_CODE = 8176
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (spec)
+# algorithmic HBM bytes per frame of the decode kernel: LLR in (8176 x 4) + packed hard
+# decision out (1022) + iteration count (4) + status (1) + ones count (4)
+BYTES_PER_FRAME = N_CODE * 4 + (N_CODE + 7) // 8 + 4 + 1 + 4
+
+
+def cpu_baseline(llr_host, n_threads):
+    """The CPU oracle (C restatement of ldpc.py's decoder, float64) timed on the host cores."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import numpy as np
+    import oracle as om
+    from ldpc_amd import codes
+    orc = om.Oracle(codes.near_earth().to_dense())
+    y = llr_host.astype(np.float64)
+    one = min(len(y), 512)
+    t0 = time.perf_counter()
+    orc.minsum(y[:one], 50, prec=64, want_soft=False, threads=1)
+    t1 = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    hard, iters, conv, _ = orc.minsum(y, 50, prec=64, want_soft=False, threads=n_threads)
+    tn = time.perf_counter() - t0
+    return dict(value=K_INFO * len(y) / tn / 1e9, unit='Gbit/s', cores=n_threads, kind='port',
+                sample=f'{len(y)} frames of the same batch (3.5 dB, <=50 iterations, float64), '
+                       f'{n_threads} OpenMP threads over frames, {tn:.2f} s wall',
+                single_core_value=K_INFO * one / t1 / 1e9, single_core_frames=one,
+                mean_iters=float(iters.mean())), iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--frames', type=int, default=1_000_000, help='frames per GPU per step')
+    ap.add_argument('--snr', type=float, default=3.5)
+    ap.add_argument('--prec', type=int, default=32, choices=(32, 64))
+    ap.add_argument('--max-iters', type=int, default=50)
+    ap.add_argument('--cpu-frames', type=int, default=16384)
+    ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--seed', type=int, default=460101)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import ldpc_amd
+    from ldpc_amd import codes
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    dev = torch.device('cuda', local_rank)
+    torch.cuda.set_device(dev)
+
+    F = args.frames
+    eng = ldpc_amd.Decoder(codes.near_earth(), device=local_rank)
+    stream = torch.cuda.current_stream()
+    eng.set_stream(stream.cuda_stream)
+    n, nbytes = eng.n, eng.nbytes
+
+    llr = torch.empty((F, n), dtype=torch.float32, device=dev)
+    hard = torch.empty((F, nbytes), dtype=torch.uint8, device=dev)
+    iters = torch.empty(F, dtype=torch.int32, device=dev)
+    conv = torch.empty(F, dtype=torch.uint8, device=dev)
+    ones = torch.empty(F, dtype=torch.int32, device=dev)
+    unc = torch.empty(F, dtype=torch.int32, device=dev)
+
+    # synthetic input: every rank draws its own frames (frame ids rank*F ...), on the device
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng.channel_awgn_device(llr, F, args.snr, seed=args.seed, first_frame=rank * F, d_uncoded=unc)
+    torch.cuda.synchronize()
+    t_channel = time.perf_counter() - t0
+
+    def step():
+        eng.decode_device(llr, F, args.max_iters, prec=args.prec, d_hard=hard, d_iters=iters,
+                          d_conv=conv, d_ones=ones)
+
+    def counters():
+        c = torch.stack([torch.tensor(F, device=dev, dtype=torch.int64),
+                         (ones != 0).sum(), ones.sum(dtype=torch.int64), iters.sum(dtype=torch.int64),
+                         unc.sum(dtype=torch.int64), (conv == 0).sum()])
+        if world > 1:
+            dist.all_reduce(c)          # the path's only exchange: error counters (RCCL)
+        return c
+
+    for _ in range(args.warmup):
+        step()
+        counters()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+          for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record(stream)
+        step()
+        ev[k][1].record(stream)
+        c = counters()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kernel_ms = [a.elapsed_time(b) for a, b in ev]
+    c = c.cpu().numpy()
+
+    if rank == 0:
+        total_frames = int(c[0])
+        value = K_INFO * total_frames * args.steps / elapsed / 1e9
+        k_ms = float(np.mean(kernel_ms))
+        achieved = BYTES_PER_FRAME * F / (k_ms * 1e-3) / 1e9
+        info = eng.launch_info(prec=args.prec)
+        traffic = None
+        prof = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
+        if os.path.exists(prof):
+            try:
+                pj = json.load(open(prof))
+                key = f'prec{args.prec}_frames{F}'
+                if key in pj:
+                    traffic = pj[key]['hbm_bytes_per_launch']
+            except Exception:
+                traffic = None
+        out = {
+            'metric': 'decoded info Gbit/s, NearEarth (8176,7154) min-sum @50 iters',
+            'value': value, 'unit': 'Gbit/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32' if args.prec == 32 else 'f64', 'data': 'synthetic',
+            'config': {'workload': f'NearEarth (8176,7154) min-sum, <=%d iterations with early stop, BPSK/AWGN '
+                                   f'%.2f dB (reference SNR definition), %d frames per GPU resident in HBM, '
+                                   f'LLR float32 in / packed hard bits + iterations + status out'
+                                   % (args.max_iters, args.snr, F),
+                       'frames_per_gpu': F, 'snr_db': args.snr, 'max_iters': args.max_iters,
+                       'parallelism': f'frames sharded over {world} GPU(s), counters all-reduced'},
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                         'kernel': 'qc_minsum_kernel', 'kernel_ms': k_ms,
+                         'algorithmic_bytes_per_frame': BYTES_PER_FRAME,
+                         'note': 'message passing runs out of LDS/registers; HBM carries only LLR-in and '
+                                 'results-out, so the HBM fraction is small by design (see DESIGN.md for the '
+                                 'on-chip budget)'},
+            'stats': {'frames': total_frames, 'mean_iters': float(c[3]) / total_frames,
+                      'fer': float(c[1]) / total_frames, 'ber': float(c[2]) / (total_frames * N_CODE),
+                      'uncoded_ber': float(c[4]) / (total_frames * N_CODE),
+                      'not_codeword': int(c[5])},
+            'launch': info,
+            'codeword_gbps': value * N_CODE / K_INFO,
+            'frames_per_s': total_frames * args.steps / elapsed,
+            'channel_fill_s': t_channel,
+        }
+        if not args.no_cpu and world == 1:
+            ncpu = min(16, os.cpu_count() or 1)
+            m = min(args.cpu_frames, F)
+            base, it_cpu = cpu_baseline(llr[:m].cpu().numpy(), ncpu)
+            out['cpu_baseline'] = base
+            if args.prec == 64:
+                out['cpu_gpu_iters_equal'] = bool(np.array_equal(it_cpu, iters[:m].cpu().numpy()))
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -83,10 +83,12 @@ void ldpc_destroy(ldpc_handle *h);
 /* Code dimensions of a handle. */
 int ldpc_get_dims(const ldpc_handle *h, int *m, int *n, int *edges);
 
-/* Make the handle launch on an existing HIP stream (hipStream_t passed as
- * void*; NULL = the handle's own stream).  No counterpart in the reference
- * (numba's default stream, ldpcCUDA.py:594-662). */
-int ldpc_set_stream(ldpc_handle *h, void *hip_stream);
+/* Make the handle launch on an existing HIP stream: hip_stream is a hipStream_t
+ * passed as void* (NULL is the legacy default stream, which is a valid choice);
+ * use_own != 0 ignores hip_stream and goes back to the stream the handle
+ * created for itself.  No counterpart in the reference (numba's default
+ * stream, ldpcCUDA.py:594-662). */
+int ldpc_set_stream(ldpc_handle *h, void *hip_stream, int use_own);
 
 /* Block until everything queued on the handle's stream has finished. */
 int ldpc_sync(ldpc_handle *h);
@@ -114,7 +116,28 @@ int ldpc_decode(ldpc_handle *h, int algo, int prec, int sign_mode, int max_iters
                 int32_t *iters, uint8_t *converged, int32_t *ones, void *soft_out);
 
 /*
- * Same, with every buffer in DEVICE memory of the handle's device; queued on
+ * Stateful decoder: same arguments and outputs as ldpc_decode, but the frames
+ * are decoded ONE AFTER ANOTHER on a decoder whose check-node messages are not
+ * cleared between frames -- the first iteration of a frame subtracts the
+ * messages the checks sent in the last completed iteration of the previous
+ * frame.  This is what re-using one reference ldpcDecoder object does
+ * (decoderSet resets only the variable nodes, ldpc.py:270-274; one decoder for
+ * all frames in evaluateCode, ldpc.py:356,377, and for all SNR points in
+ * evaluateCodeAtSingleTransmission, ldpc.py:397,424).  The state lives in the
+ * handle (one per prec) and survives across calls; ldpc_reset_state returns
+ * the handle to a freshly constructed decoder.  One workgroup, sequential:
+ * meant for exact reproduction of the reference's CPU evaluation, not for
+ * throughput.
+ */
+int ldpc_decode_chained(ldpc_handle *h, int algo, int prec, int sign_mode, int max_iters,
+                        int64_t n_frames, const void *llr, int llr_bits, uint8_t *hard_bits,
+                        int32_t *iters, uint8_t *converged, int32_t *ones, void *soft_out);
+
+/* Forget the chained decoder's check-node messages (= a new ldpcDecoder(H), ldpc.py:114-133). */
+int ldpc_reset_state(ldpc_handle *h);
+
+/*
+ * Same as ldpc_decode, with every buffer in DEVICE memory of the handle's device; queued on
  * the handle's stream, returns without waiting.  llr_scale multiplies the
  * channel values on load (1.0 for min-sum parity with the reference, whose
  * "LLR" is the raw channel value; 2/sigma^2 for sum-product).

@@ -78,6 +78,9 @@ struct DecodeArgs {
     uint8_t *conv;         // [frames] or null
     int32_t *ones;         // [frames] or null
     void *soft;            // [frames][n] T or null
+    unsigned char *chain;  // null, or the persistent check-node state of a chained decoder:
+                           // frames are decoded one after another (grid of 1 workgroup) and the
+                           // check rows' last outgoing messages carry over from frame to frame
 };
 
 // ---------------------------------------------------------------- small helpers
@@ -188,6 +191,18 @@ qc_minsum_kernel(const QcTables tb, const DecodeArgs a)
     const int nbytes = (n + 7) >> 3;
     const T INF = t_inf(T(0));
 
+    // outgoing messages of this thread's check row, compressed
+    T omin1 = T(0), omin2 = T(0);
+    ST osigns = 0;
+    uint32_t oidx = 0;
+    T2 *chain_mins = reinterpret_cast<T2 *>(a.chain);
+    Meta *chain_meta = reinterpret_cast<Meta *>(a.chain + (size_t)slots * sizeof(T2));
+    if (a.chain && live) {
+        const T2 mm = chain_mins[slot];
+        const Meta mt = chain_meta[slot];
+        omin1 = mm.x; omin2 = mm.y; osigns = mt.signs; oidx = mt.idx;
+    }
+
     const int64_t n_fblocks = (a.n_frames + FPW - 1) / FPW;
     for (int64_t fb = blockIdx.x; fb < n_fblocks; fb += gridDim.x) {
         const int64_t frame = fb * FPW + f;
@@ -207,10 +222,12 @@ qc_minsum_kernel(const QcTables tb, const DecodeArgs a)
             }
         }
         if (tid < 3 * FPW) flags[tid] = 0;
-        // fresh check nodes: every outgoing message is +0 (checkNode.__init__, ldpc.py:121)
-        T omin1 = T(0), omin2 = T(0);
-        ST osigns = 0;
-        uint32_t oidx = 0;
+        if (!a.chain) {
+            // fresh check nodes: every outgoing message is +0 (checkNode.__init__, ldpc.py:121).
+            // A chained decoder keeps them instead: decoderSet resets only the variable
+            // nodes (ldpc.py:270-274).
+            omin1 = T(0); omin2 = T(0); osigns = 0; oidx = 0;
+        }
         uint32_t act_mask = 0;       // frame slots still iterating (same value in every thread)
 #pragma unroll
         for (int ff = 0; ff < FPW; ++ff)
@@ -223,10 +240,10 @@ qc_minsum_kernel(const QcTables tb, const DecodeArgs a)
             const bool active = (act_mask >> f) & 1u;
             const int par = it & 1;
             // ================= check pass (+ syndrome of the current posterior)
+            T min1 = INF, min2 = INF;
+            uint32_t idx = 0;
+            ST ns = 0;
             if (active && live) {
-                T min1 = INF, min2 = INF;
-                uint32_t idx = 0;
-                ST ns = 0;
                 unsigned long long synd = 0;
 #pragma unroll 4
                 for (int e = 0; e < deg; ++e) {
@@ -251,7 +268,6 @@ qc_minsum_kernel(const QcTables tb, const DecodeArgs a)
                 if (a.sign_mode == LDPC_SIGN_CORRECTED) S ^= (uint32_t)deg & 1u;
                 const ST full = (deg >= (int)(8 * sizeof(ST))) ? ~(ST)0 : ((((ST)1) << deg) - 1);
                 ns ^= S ? full : (ST)0;
-                omin1 = min1; omin2 = min2; osigns = ns; oidx = idx;
                 T2 mm; mm.x = min1; mm.y = min2;
                 mins[slot] = mm;
                 Meta mt; mt.signs = ns; mt.idx = idx;
@@ -275,6 +291,9 @@ qc_minsum_kernel(const QcTables tb, const DecodeArgs a)
             }
             act_mask = next_mask;
             if (act_mask == 0) break;
+            // the row's messages of this iteration become its "previous" messages only now:
+            // a frame that stops here keeps the ones its last completed iteration sent
+            if (((act_mask >> f) & 1u) && live) { omin1 = min1; omin2 = min2; osigns = ns; oidx = idx; }
             if (tid < FPW) flags[(par ^ 1) * FPW + tid] = 0;
             // ================= variable pass (ldpc.py:295-311, 321-323)
             if (((act_mask >> f) & 1u) && live) {
@@ -356,6 +375,12 @@ qc_minsum_kernel(const QcTables tb, const DecodeArgs a)
         }
         __syncthreads();
     }
+    if (a.chain && live) {
+        T2 mm; mm.x = omin1; mm.y = omin2;
+        chain_mins[slot] = mm;
+        Meta mt; mt.signs = osigns; mt.idx = oidx;
+        chain_meta[slot] = mt;
+    }
 }
 
 // ---------------------------------------------------------------- CSR min-sum kernel
@@ -363,7 +388,7 @@ qc_minsum_kernel(const QcTables tb, const DecodeArgs a)
 // Arbitrary sparse H.  One 256-thread workgroup per frame; posteriors and the
 // compressed row states live in a per-workgroup slice of a global workspace
 // (they stay in L2 for the sizes this path is used for).  Same arithmetic as
-// the QC kernel.
+// the QC kernel; the syndrome is a pass of its own here.
 template <typename T>
 __global__ void __launch_bounds__(256)
 csr_minsum_kernel(const CsrTables tb, const DecodeArgs a, unsigned char *workspace, size_t ws_stride)
@@ -391,11 +416,13 @@ csr_minsum_kernel(const CsrTables tb, const DecodeArgs a, unsigned char *workspa
             ych[c] = yv;
             post[c] = yv;
         }
-        for (int r = tid; r < m; r += blockDim.x) {
-            T2 z; z.x = T(0); z.y = T(0);
-            mins[r] = z;
-            Meta mt; mt.signs = 0; mt.idx = 0; mt.pad = 0;
-            meta[r] = mt;
+        if (!a.chain) {
+            for (int r = tid; r < m; r += blockDim.x) {
+                T2 z; z.x = T(0); z.y = T(0);
+                mins[r] = z;
+                Meta mt; mt.signs = 0; mt.idx = 0; mt.pad = 0;
+                meta[r] = mt;
+            }
         }
         if (tid < 2) flags[tid] = 0;
         if (tid == 0) ones_cnt = 0;
@@ -403,19 +430,33 @@ csr_minsum_kernel(const CsrTables tb, const DecodeArgs a, unsigned char *workspa
         int it = 0;
         for (;; ++it) {
             const int par = it & 1;
+            // syndrome of the current posterior (isCodeword, ldpc.py:249-268)
             bool bad_row = false;
+            for (int r = tid; r < m; r += blockDim.x) {
+                uint32_t sy = 0;
+                for (int e = tb.row_ptr[r]; e < tb.row_ptr[r + 1]; ++e)
+                    sy ^= (uint32_t)(post[tb.col_idx[e]] > T(0));
+                bad_row |= (sy != 0);
+            }
+            if (bad_row) flags[par] = 1;
+            __syncthreads();
+            const int bad = flags[par];
+            if (bad == 0 || it >= a.max_iters) {
+                if (tid == 0) { result[0] = it; result[1] = (bad == 0); }
+                break;
+            }
+            if (tid == 0) flags[par ^ 1] = 0;
+            // check pass
             for (int r = tid; r < m; r += blockDim.x) {
                 const int e0 = tb.row_ptr[r], e1 = tb.row_ptr[r + 1];
                 const T2 om = mins[r];
                 const Meta ot = meta[r];
                 T min1 = INF, min2 = INF;
-                uint32_t idx = 0, sy = 0;
+                uint32_t idx = 0;
                 uint64_t ns = 0;
                 for (int e = e0; e < e1; ++e) {
                     const int k = e - e0;
-                    const T p = post[tb.col_idx[e]];
-                    sy ^= (uint32_t)(p > T(0));
-                    const T v = p - rebuild<T, true>(om, ot, k);
+                    const T v = post[tb.col_idx[e]] - rebuild<T, true>(om, ot, k);
                     ns |= (uint64_t)(v < T(0)) << k;
                     const T av = t_abs(v);
                     const bool lt = av < min1;
@@ -432,16 +473,9 @@ csr_minsum_kernel(const CsrTables tb, const DecodeArgs a, unsigned char *workspa
                 mins[r] = mm;
                 Meta mt; mt.signs = ns; mt.idx = idx; mt.pad = 0;
                 meta[r] = mt;
-                bad_row |= (sy != 0);
             }
-            if (bad_row) flags[par] = 1;
             __syncthreads();
-            const int bad = flags[par];
-            if (bad == 0 || it >= a.max_iters) {
-                if (tid == 0) { result[0] = it; result[1] = (bad == 0); }
-                break;
-            }
-            if (tid == 0) flags[par ^ 1] = 0;
+            // variable pass
             for (int c = tid; c < n; c += blockDim.x) {
                 T acc = T(0);
                 for (int k = tb.col_ptr[c]; k < tb.col_ptr[c + 1]; ++k) {
@@ -614,6 +648,8 @@ struct ldpc_handle {
     std::vector<void *> tables;   // device allocations owned by the handle
     // staging for the host entry points
     DevBuf b_llr, b_hard, b_iters, b_conv, b_ones, b_soft, b_sig, b_unc, b_cnt, b_pf, b_ws;
+    // check-node state of the chained (stateful) decoder, one per arithmetic width
+    DevBuf b_chain32, b_chain64;
 };
 
 struct Launch {
@@ -666,7 +702,7 @@ extern "C" void ldpc_destroy(ldpc_handle *h)
     if (h->own_stream) { (void)hipStreamSynchronize(h->own_stream); }
     for (void *p : h->tables) (void)hipFree(p);
     DevBuf *bufs[] = {&h->b_llr, &h->b_hard, &h->b_iters, &h->b_conv, &h->b_ones, &h->b_soft,
-                      &h->b_sig, &h->b_unc, &h->b_cnt, &h->b_pf, &h->b_ws};
+                      &h->b_sig, &h->b_unc, &h->b_cnt, &h->b_pf, &h->b_ws, &h->b_chain32, &h->b_chain64};
     for (DevBuf *b : bufs) b->release();
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
@@ -801,10 +837,10 @@ extern "C" int ldpc_get_dims(const ldpc_handle *h, int *m, int *n, int *edges)
     return 0;
 }
 
-extern "C" int ldpc_set_stream(ldpc_handle *h, void *hip_stream)
+extern "C" int ldpc_set_stream(ldpc_handle *h, void *hip_stream, int use_own)
 {
     if (!h) return fail(LDPC_E_ARG, "handle is NULL");
-    h->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : h->own_stream;
+    h->stream = use_own ? h->own_stream : reinterpret_cast<hipStream_t>(hip_stream);
     return 0;
 }
 
@@ -839,10 +875,11 @@ static int qc_pick(const ldpc_handle *h, Launch *L)
 }
 
 template <typename T, bool S64>
-static int qc_select(const ldpc_handle *h, Launch *L)
+static int qc_select(const ldpc_handle *h, bool chained, Launch *L)
 {
     const int cpt = h->cols_per_thread;
     const int thr1 = h->qc.mb * h->qc.Zp;
+    if (cpt <= 8 && chained) return qc_pick<T, S64, 8, 1>(h, L);
     if (cpt <= 8) {
         // pack several short frames into one workgroup while threads and LDS allow
         if (thr1 * 4 <= 1024 && qc_lds_bytes<T, S64, 8, 4>(h->qc) <= h->lds_max / 2) return qc_pick<T, S64, 8, 4>(h, L);
@@ -862,7 +899,7 @@ static size_t csr_ws_stride(const ldpc_handle *h, int prec)
     return (b + 255) & ~(size_t)255;
 }
 
-static int select_launch(ldpc_handle *h, int algo, int prec, int64_t n_frames, Launch *L)
+static int select_launch(ldpc_handle *h, int algo, int prec, int64_t n_frames, bool chained, Launch *L)
 {
     if (algo != LDPC_ALGO_MINSUM)
         return fail(LDPC_E_UNSUPPORTED, "algorithm %d is not available in this build", algo);
@@ -871,8 +908,8 @@ static int select_launch(ldpc_handle *h, int algo, int prec, int64_t n_frames, L
     if (h->is_qc) {
         const bool s64 = h->max_row_deg > 32;
         int rc;
-        if (prec == 32) rc = s64 ? qc_select<float, true>(h, L) : qc_select<float, false>(h, L);
-        else            rc = s64 ? qc_select<double, true>(h, L) : qc_select<double, false>(h, L);
+        if (prec == 32) rc = s64 ? qc_select<float, true>(h, chained, L) : qc_select<float, false>(h, chained, L);
+        else            rc = s64 ? qc_select<double, true>(h, chained, L) : qc_select<double, false>(h, chained, L);
         if (rc) return rc;
         if (L->lds > h->lds_max)
             return fail(LDPC_E_UNSUPPORTED, "code needs %zu bytes of LDS per workgroup, device has %zu", L->lds, h->lds_max);
@@ -882,6 +919,7 @@ static int select_launch(ldpc_handle *h, int algo, int prec, int64_t n_frames, L
         if (per_cu < 1) per_cu = 1;
         const int64_t fblocks = (n_frames + L->fpw - 1) / L->fpw;
         L->grid = (int)std::max<int64_t>(1, std::min<int64_t>(fblocks, (int64_t)h->n_cu * per_cu));
+        if (chained) L->grid = 1;
     } else {
         L->fn = prec == 32 ? reinterpret_cast<const void *>(&csr_minsum_kernel<float>)
                            : reinterpret_cast<const void *>(&csr_minsum_kernel<double>);
@@ -889,14 +927,24 @@ static int select_launch(ldpc_handle *h, int algo, int prec, int64_t n_frames, L
         L->fpw = 1;
         L->lds = 0;
         L->grid = (int)std::max<int64_t>(1, std::min<int64_t>(n_frames, (int64_t)h->n_cu * 4));
+        if (chained) L->grid = 1;
     }
     return 0;
+}
+
+// Bytes of persistent check-node state of a chained decoder.
+static size_t chain_bytes(const ldpc_handle *h, int prec)
+{
+    if (!h->is_qc) return 0;   // CSR: the whole workspace slice persists (csr_ws_stride)
+    const size_t slots = (size_t)h->qc.mb * h->qc.Zp;
+    const size_t ts = prec == 64 ? 8 : 4;
+    return slots * 2 * ts + slots * (h->max_row_deg > 32 ? 16 : 8);
 }
 
 static int launch_decode(ldpc_handle *h, int algo, int prec, const DecodeArgs &args)
 {
     Launch L;
-    int rc = select_launch(h, algo, prec, args.n_frames, &L);
+    int rc = select_launch(h, algo, prec, args.n_frames, args.chain != nullptr, &L);
     if (rc) return rc;
     if (h->is_qc) {
         QcTables tb = h->qc;
@@ -905,10 +953,11 @@ static int launch_decode(ldpc_handle *h, int algo, int prec, const DecodeArgs &a
         HIP_TRY(hipLaunchKernel(L.fn, dim3(L.grid), dim3(L.block), kargs, L.lds, h->stream));
     } else {
         size_t stride = csr_ws_stride(h, prec);
-        if ((rc = h->b_ws.ensure(stride * (size_t)L.grid))) return rc;
+        if (!args.chain && (rc = h->b_ws.ensure(stride * (size_t)L.grid))) return rc;
         CsrTables tb = h->csr;
         DecodeArgs a = args;
-        unsigned char *ws = reinterpret_cast<unsigned char *>(h->b_ws.p);
+        // chained: the persistent buffer IS the workspace of the single workgroup
+        unsigned char *ws = args.chain ? args.chain : reinterpret_cast<unsigned char *>(h->b_ws.p);
         void *kargs[] = {&tb, &a, &ws, &stride};
         HIP_TRY(hipLaunchKernel(L.fn, dim3(L.grid), dim3(L.block), kargs, 0, h->stream));
     }
@@ -930,7 +979,7 @@ extern "C" int ldpc_get_launch_info(ldpc_handle *h, int algo, int prec, int *gri
 {
     if (!h) return fail(LDPC_E_ARG, "handle is NULL");
     Launch L;
-    int rc = select_launch(h, algo, prec, INT64_MAX / 2, &L);
+    int rc = select_launch(h, algo, prec, INT64_MAX / 2, false, &L);
     if (rc) return rc;
     if (grid) *grid = L.grid;
     if (block) *block = L.block;
@@ -952,13 +1001,38 @@ extern "C" int ldpc_decode_device(ldpc_handle *h, int algo, int prec, int sign_m
     DecodeArgs a;
     a.llr = d_llr; a.llr_f64 = llr_bits == 64; a.llr_scale = llr_scale; a.n_frames = n_frames; a.max_iters = max_iters;
     a.sign_mode = sign_mode; a.hard = d_hard_bits; a.iters = d_iters; a.conv = d_converged;
-    a.ones = d_ones; a.soft = d_soft_out;
+    a.ones = d_ones; a.soft = d_soft_out; a.chain = nullptr;
     return launch_decode(h, algo, prec, a);
 }
 
-extern "C" int ldpc_decode(ldpc_handle *h, int algo, int prec, int sign_mode, int max_iters,
-                           int64_t n_frames, const void *llr, int llr_bits, uint8_t *hard_bits,
-                           int32_t *iters, uint8_t *converged, int32_t *ones, void *soft_out)
+static int chain_state(ldpc_handle *h, int prec, unsigned char **out)
+{
+    DevBuf &b = prec == 64 ? h->b_chain64 : h->b_chain32;
+    if (!b.p) {
+        const size_t bytes = h->is_qc ? chain_bytes(h, prec) : csr_ws_stride(h, prec);
+        int rc = b.ensure(bytes);
+        if (rc) return rc;
+        HIP_TRY(hipMemsetAsync(b.p, 0, bytes, h->stream));   // all-zero = fresh check nodes
+    }
+    *out = reinterpret_cast<unsigned char *>(b.p);
+    return 0;
+}
+
+extern "C" int ldpc_reset_state(ldpc_handle *h)
+{
+    if (!h) return fail(LDPC_E_ARG, "handle is NULL");
+    HIP_TRY(hipSetDevice(h->device));
+    for (int prec : {32, 64}) {
+        DevBuf &b = prec == 64 ? h->b_chain64 : h->b_chain32;
+        if (b.p) HIP_TRY(hipMemsetAsync(b.p, 0, b.cap, h->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+static int decode_host(ldpc_handle *h, bool chained, int algo, int prec, int sign_mode, int max_iters,
+                       int64_t n_frames, const void *llr, int llr_bits, uint8_t *hard_bits,
+                       int32_t *iters, uint8_t *converged, int32_t *ones, void *soft_out)
 {
     int rc = check_common(h, max_iters, n_frames, sign_mode);
     if (rc) return rc;
@@ -975,6 +1049,8 @@ extern "C" int ldpc_decode(ldpc_handle *h, int algo, int prec, int sign_mode, in
         (rc = h->b_ones.ensure((size_t)chunk * 4)))
         return rc;
     if (soft_out && (rc = h->b_soft.ensure((size_t)chunk * n * ts))) return rc;
+    unsigned char *chain = nullptr;
+    if (chained && (rc = chain_state(h, prec, &chain))) return rc;
     for (int64_t f0 = 0; f0 < n_frames; f0 += chunk) {
         const int64_t nf = std::min<int64_t>(chunk, n_frames - f0);
         HIP_TRY(hipMemcpyAsync(h->b_llr.p, reinterpret_cast<const unsigned char *>(llr) + (size_t)f0 * n * ls,
@@ -987,6 +1063,7 @@ extern "C" int ldpc_decode(ldpc_handle *h, int algo, int prec, int sign_mode, in
         a.conv = reinterpret_cast<uint8_t *>(h->b_conv.p);
         a.ones = reinterpret_cast<int32_t *>(h->b_ones.p);
         a.soft = soft_out ? h->b_soft.p : nullptr;
+        a.chain = chain;
         if ((rc = launch_decode(h, algo, prec, a))) return rc;
         if (hard_bits) HIP_TRY(hipMemcpyAsync(hard_bits + (size_t)f0 * nbytes, h->b_hard.p, (size_t)nf * nbytes, hipMemcpyDeviceToHost, h->stream));
         if (iters) HIP_TRY(hipMemcpyAsync(iters + f0, h->b_iters.p, (size_t)nf * 4, hipMemcpyDeviceToHost, h->stream));
@@ -996,6 +1073,22 @@ extern "C" int ldpc_decode(ldpc_handle *h, int algo, int prec, int sign_mode, in
         HIP_TRY(hipStreamSynchronize(h->stream));
     }
     return 0;
+}
+
+extern "C" int ldpc_decode(ldpc_handle *h, int algo, int prec, int sign_mode, int max_iters,
+                           int64_t n_frames, const void *llr, int llr_bits, uint8_t *hard_bits,
+                           int32_t *iters, uint8_t *converged, int32_t *ones, void *soft_out)
+{
+    return decode_host(h, false, algo, prec, sign_mode, max_iters, n_frames, llr, llr_bits, hard_bits,
+                       iters, converged, ones, soft_out);
+}
+
+extern "C" int ldpc_decode_chained(ldpc_handle *h, int algo, int prec, int sign_mode, int max_iters,
+                                   int64_t n_frames, const void *llr, int llr_bits, uint8_t *hard_bits,
+                                   int32_t *iters, uint8_t *converged, int32_t *ones, void *soft_out)
+{
+    return decode_host(h, true, algo, prec, sign_mode, max_iters, n_frames, llr, llr_bits, hard_bits,
+                       iters, converged, ones, soft_out);
 }
 
 static int launch_channel(ldpc_handle *h, double snr_db, uint64_t seed, uint32_t stream_id,
@@ -1058,7 +1151,7 @@ extern "C" int ldpc_eval_awgn(ldpc_handle *h, int algo, int prec, int sign_mode,
             a.iters = reinterpret_cast<int32_t *>(h->b_iters.p);
             a.conv = reinterpret_cast<uint8_t *>(h->b_conv.p);
             a.ones = reinterpret_cast<int32_t *>(h->b_ones.p);
-            a.soft = nullptr;
+            a.soft = nullptr; a.chain = nullptr;
             if ((rc = launch_decode(h, algo, prec, a))) return rc;
             const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((nf + 255) / 256, 1024));
             hipLaunchKernelGGL(accumulate_kernel, dim3(grid), dim3(256), 0, h->stream, nf,

@@ -102,8 +102,12 @@ class Decoder:
 
     # -- stream control
     def set_stream(self, hip_stream):
-        """hip_stream: integer hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) or None."""
-        _check(self._L.ldpc_set_stream(self._h, ctypes.c_void_p(hip_stream) if hip_stream else None))
+        """hip_stream: integer hipStream_t, e.g. torch.cuda.current_stream().cuda_stream
+        (0 = the legacy default stream); None = back to the handle's own stream."""
+        if hip_stream is None:
+            _check(self._L.ldpc_set_stream(self._h, None, 1))
+        else:
+            _check(self._L.ldpc_set_stream(self._h, ctypes.c_void_p(int(hip_stream)), 0))
 
     def sync(self):
         _check(self._L.ldpc_sync(self._h))
@@ -115,10 +119,18 @@ class Decoder:
         return dict(grid=g.value, block=b.value, lds_bytes=l.value, frames_per_wg=f.value)
 
     # -- host entry point
+    def reset_state(self):
+        """Chained decoding starts from fresh check nodes again."""
+        _check(self._L.ldpc_reset_state(self._h))
+
     def decode(self, llr, max_iters=50, prec=64, algo=ALGO_MINSUM, sign_mode=SIGN_REFERENCE,
-               want_soft=False, want_hard=True):
+               want_soft=False, want_hard=True, chained=False):
         """Decode host frames.  llr: [F, n] (or [n]) channel values; float64 input is
         passed through as float64, anything else as float32.
+
+        chained=True decodes the frames one after another on the handle's stateful
+        decoder (check-node messages carry over, as when one reference ldpcDecoder
+        object is re-used); the default gives every frame a fresh decoder.
 
         Returns dict(hard=uint8 [F, n] 0/1 (or None), iters=int32 [F], converged=uint8 [F],
         ones=int32 [F], soft=float32/float64 [F, n] or None)."""
@@ -133,10 +145,11 @@ class Decoder:
         conv = np.zeros(F, np.uint8)
         ones = np.zeros(F, np.int32)
         soft = np.zeros((F, n), np.float64 if prec == 64 else np.float32) if want_soft else None
-        _check(self._L.ldpc_decode(self._h, algo, prec, sign_mode, int(max_iters), F, y.ctypes.data, llr_bits,
+        fn = self._L.ldpc_decode_chained if chained else self._L.ldpc_decode
+        _check(fn(self._h, algo, prec, sign_mode, int(max_iters), F, y.ctypes.data, llr_bits,
                                    hard.ctypes.data if want_hard else None, iters.ctypes.data,
                                    conv.ctypes.data, ones.ctypes.data,
-                                   soft.ctypes.data if want_soft else None))
+              soft.ctypes.data if want_soft else None))
         bits = None
         if want_hard:
             bits = np.unpackbits(hard, axis=1, bitorder='little')[:, :n]

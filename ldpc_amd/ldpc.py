@@ -5,13 +5,18 @@ in float64 (the reference's LDPC_DECIMAL_DATA_TYPE, ldpc.py:29), which makes
 hard decisions, soft outputs and iteration counts bit-identical to the
 reference's for a freshly constructed decoder.
 
-Deliberate differences (each is also noted where it occurs):
-  * a decoder object does not carry check-node messages from one
-    decoderMainLoop call to the next (the reference's decoderSet only resets
-    variable nodes, ldpc.py:270-274); every call behaves like the first call
-    on a new reference decoder;
-  * testCodeUsingMultiprocessing runs all transmissions of an SNR point as one
-    GPU batch instead of a 2-process pool (ldpc.py:454-458).
+The reference's decoder object is stateful -- decoderSet only resets variable
+nodes (ldpc.py:270-274), so check-node messages of the previous frame leak into
+the first iteration of the next one.  ldpcDecoder, evaluateCode (one decoder for
+all frames, ldpc.py:356,377) and evaluateCodeAtSingleTransmission (one decoder
+for all SNR points, ldpc.py:397,424) reproduce that through the library's
+chained decode; pass freshDecoderPerFrame=True to evaluateCode for independent
+frames decoded in parallel.
+
+Deliberate difference: testCodeUsingMultiprocessing runs all transmissions of
+an SNR point as one GPU batch (each with a fresh decoder, as each pool task of
+the reference builds its own, ldpc.py:397) instead of a 2-process pool
+(ldpc.py:454-458).
 """
 import copy
 import hashlib
@@ -82,7 +87,12 @@ def _engine_for(H, device=None):
 
 
 class ldpcDecoder:
-    """Mirror of ldpc.ldpcDecoder (ldpc.py:223-337)."""
+    """Mirror of ldpc.ldpcDecoder (ldpc.py:223-337).
+
+    Like the reference object it is STATEFUL: decoderSet resets only the variable
+    nodes (ldpc.py:270-274), so the check nodes start a frame with the messages
+    they sent in the last completed iteration of the previous frame decoded by
+    this object.  Each ldpcDecoder therefore owns its own engine handle."""
 
     def __init__(self, H, device=None):
         self.parityMatrix = H
@@ -94,11 +104,11 @@ class ldpcDecoder:
         self.numberOfCheckNodes = m
         self.codewordLength = n
         self.softVector = np.zeros(n, dtype=LDPC_DECIMAL_DATA_TYPE)
-        self._engine = _engine_for(H, device)
+        self._engine = Decoder(H, device=LDPC_HIP_DEVICE if device is None else device)
 
     def isCodeword(self, modulatedVector):
         """('Codeword' | 'Not a codeword', hard decision int64[n]) (ldpc.py:249-268).
-        Evaluated by the decode kernel with an iteration budget of 0."""
+        Evaluated by the decode kernel with an iteration budget of 0 (no state is touched)."""
         r = self._engine.decode(np.asarray(modulatedVector, dtype=LDPC_DECIMAL_DATA_TYPE), 0, prec=64)
         status = 'Codeword' if r['converged'][0] else 'Not a codeword'
         return status, r['hard'][0].astype(LDPC_INT_DATA_TYPE)
@@ -106,7 +116,7 @@ class ldpcDecoder:
     def decoderMainLoop(self, fromChannel, maxNumberOfIterations):
         """-> (status, binaryVector int64[n], softVector float64[n], iterations) (ldpc.py:326-337)"""
         y = np.asarray(fromChannel, dtype=LDPC_DECIMAL_DATA_TYPE)
-        r = self._engine.decode(y, maxNumberOfIterations, prec=64, want_soft=True)
+        r = self._engine.decode(y, maxNumberOfIterations, prec=64, want_soft=True, chained=True)
         it = int(r['iters'][0])
         status = 'Codeword' if r['converged'][0] else 'Not a codeword'
         # zero iterations: the reference returns a copy of its input (ldpc.py:328)
@@ -114,10 +124,13 @@ class ldpcDecoder:
         self.softVector = soft
         return status, r['hard'][0].astype(LDPC_INT_DATA_TYPE), soft, it
 
-    def decodeBatch(self, fromChannel, maxNumberOfIterations, wantSoft=False):
-        """Many frames at once ([F, n]); not in the reference.  -> engine result dict."""
+    def decodeBatch(self, fromChannel, maxNumberOfIterations, wantSoft=False, chained=True):
+        """Many frames ([F, n]) in one call; not in the reference.  chained=True decodes
+        them in order on this object's state (= calling decoderMainLoop F times);
+        chained=False gives every frame a fresh decoder and runs them in parallel.
+        -> engine result dict."""
         return self._engine.decode(np.asarray(fromChannel, dtype=LDPC_DECIMAL_DATA_TYPE),
-                                   maxNumberOfIterations, prec=64, want_soft=wantSoft)
+                                   maxNumberOfIterations, prec=64, want_soft=wantSoft, chained=chained)
 
 
 def testModulationAndSlicingRoundTrip():
@@ -132,13 +145,14 @@ def _status(flag):
 
 
 def evaluateCode(numberOfTransmissions, seed, SNRpoints, messageSize, codewordSize, numberOfIterations, H,
-                 G='None'):
+                 G='None', freshDecoderPerFrame=False):
     """SNR x transmissions sweep of the all-zero codeword (ldpc.py:350-388).
 
     As in the reference the noise comes from the module-global LDPC_LOCAL_PRNG
     (the seed argument only has to be positive, ldpc.py:353-355, 372), in
     float64, and berUncoded is reported as 0 (ldpc.py:374).  All frames are
-    drawn first, in the reference's order, and decoded as one GPU batch."""
+    drawn first, in the reference's order, then decoded in that order on one
+    stateful decoder (or independently, in parallel, with freshDecoderPerFrame)."""
     assert (seed > 0)
     assert hasattr(SNRpoints, "__len__")
     decoder = ldpcDecoder(H)
@@ -153,7 +167,7 @@ def evaluateCode(numberOfTransmissions, seed, SNRpoints, messageSize, codewordSi
             meta.append((SNR, sigma, sigmaActual))
     if frames:
         start = time.time()
-        r = decoder.decodeBatch(np.stack(frames), numberOfIterations)
+        r = decoder.decodeBatch(np.stack(frames), numberOfIterations, chained=not freshDecoderPerFrame)
         timeTotal = time.time() - start
         for k, (SNR, sigma, sigmaActual) in enumerate(meta):
             berDecoded = int(np.count_nonzero(r['hard'][k] != codeword))
@@ -231,7 +245,7 @@ def testCodeUsingMultiprocessing(seed, SNRpoints, messageSize, codewordSize, num
             frames += f
             meta += mt
         if frames:
-            r = decoder.decodeBatch(np.stack(frames), numberOfIterations)
+            r = decoder.decodeBatch(np.stack(frames), numberOfIterations, chained=False)
             for k, (SNR, sigma, sigmaActual, berUncoded, codeword) in enumerate(meta):
                 one = common.berStatistics()
                 one.addEntry(SNR, sigma, sigmaActual, berUncoded,

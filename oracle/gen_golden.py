@@ -176,12 +176,50 @@ def run_job(job):
                 llr0=Y[0].copy())
 
 
+def gen_chained():
+    """ONE reference decoder object decoding several frames in a row, as
+    ldpc.evaluateCode does (ldpc.py:356, 377): the check nodes keep the messages
+    of the previous frame (decoderSet resets only variable nodes, ldpc.py:270-274)."""
+    ref = load_reference()
+    out = {}
+    for name, seed, snr, nfr in (('nearEarth', 460201, 3.4, 6), ('wifi_5_6', 7101, 7.0, 8),
+                                 ('rand_24_48', 8101, 4.0, 16)):
+        H = build_code(name)
+        Y = make_llrs(seed, snr, H.shape[1], nfr)
+        if name == 'nearEarth':
+            # the frame evaluateCodeAtSingleTransmission decodes at every SNR point (ldpc.py:417-418)
+            Y[1, :] = -1.0
+            Y[1, 0] = 1.0
+            Y[2] = Y[1]
+        dec = ref.ldpcDecoder(H)
+        iters, conv, hard, sha = [], [], [], []
+        for k in range(nfr):
+            status, binv, soft, it = dec.decoderMainLoop(Y[k].astype(np.float64), MAX_ITERS)
+            soft = np.ascontiguousarray(soft, dtype=np.float64)
+            iters.append(it)
+            conv.append(status == 'Codeword')
+            hard.append(np.packbits(np.asarray(binv, dtype=np.uint8), bitorder='little'))
+            sha.append(np.frombuffer(hashlib.sha256(soft.tobytes()).digest(), dtype=np.uint8))
+        out[f'{name}_llr'] = Y
+        out[f'{name}_iters'] = np.array(iters, np.int32)
+        out[f'{name}_conv'] = np.array(conv, np.uint8)
+        out[f'{name}_hard'] = np.stack(hard)
+        out[f'{name}_soft_sha256'] = np.stack(sha)
+        print('chained', name, iters, conv)
+    np.savez_compressed(os.path.join(OUT, 'chained_decoder.npz'), **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--quick', action='store_true', help='2 frames per point (plumbing check)')
     ap.add_argument('--jobs', type=int, default=8)
+    ap.add_argument('--only-chained', action='store_true', help='only (re)generate chained_decoder.npz')
     args = ap.parse_args()
     nf = 2 if args.quick else None
+    os.makedirs(OUT, exist_ok=True)
+    gen_chained()
+    if args.only_chained:
+        return
 
     plan = []   # (code, seed, snr, frames, special)
     for i, snr in enumerate([3.0, 3.2, 3.4, 3.5, 3.6, 4.5]):

@@ -95,10 +95,12 @@ static int f32_syndrome_is_zero(const oracle_graph *g, const float *x) { SYNDROM
 
 /* Batch drivers.  y: [frames][n]; hard: [frames][n] bytes 0/1 or NULL;
  * iters: [frames]; conv: [frames]; soft: [frames][n] or NULL.
- * threads <= 0 -> 1 thread.  Returns 0, or -1 on allocation failure. */
+ * state: NULL = fresh decoder per frame; else [E] check-to-variable messages of
+ * a re-used decoder (in/out, row-major edge order), frames decoded in order on
+ * one thread.  threads <= 0 -> 1 thread.  Returns 0, or -1 on allocation failure. */
 #define BATCH_BODY(REAL_T, PFX)                                               \
     int fail = 0;                                                             \
-    if (threads <= 0) threads = 1;                                            \
+    if (threads <= 0 || state) threads = 1;                                   \
     _Pragma("omp parallel num_threads(threads)")                              \
     {                                                                         \
         REAL_T *c2v = (REAL_T *)malloc(sizeof(REAL_T) * (size_t)(g->E + 1));  \
@@ -110,12 +112,12 @@ static int f32_syndrome_is_zero(const oracle_graph *g, const float *x) { SYNDROM
         } else {                                                              \
             _Pragma("omp for schedule(dynamic, 1)")                           \
             for (int64_t f = 0; f < n_frames; ++f)                            \
-                PFX##decode_frame(g, sign_mode, max_iters,                    \
+                PFX##decode_frame(g, sign_mode, state != NULL, max_iters,     \
                                   y + (size_t)f * g->n,                       \
                                   hard ? hard + (size_t)f * g->n : NULL,      \
                                   iters + f, conv + f,                        \
                                   soft ? soft + (size_t)f * g->n : NULL,      \
-                                  c2v, v2c, post);                            \
+                                  state ? state : c2v, v2c, post);            \
         }                                                                     \
         free(c2v); free(v2c); free(post);                                     \
     }                                                                         \
@@ -123,14 +125,14 @@ static int f32_syndrome_is_zero(const oracle_graph *g, const float *x) { SYNDROM
 
 int oracle_minsum_f64(const oracle_graph *g, int sign_mode, int max_iters, int64_t n_frames,
                       const double *y, uint8_t *hard, int32_t *iters, uint8_t *conv,
-                      double *soft, int threads)
+                      double *soft, double *state, int threads)
 {
     BATCH_BODY(double, f64_)
 }
 
 int oracle_minsum_f32(const oracle_graph *g, int sign_mode, int max_iters, int64_t n_frames,
                       const float *y, uint8_t *hard, int32_t *iters, uint8_t *conv,
-                      float *soft, int threads)
+                      float *soft, float *state, int threads)
 {
     BATCH_BODY(float, f32_)
 }

@@ -17,8 +17,11 @@
  *   checkNode.setSign                  ldpc.py:135-141
  *   checkNode.calcOutgoingValues       ldpc.py:174-202
  *   checkNodesToVariableNodes/update   ldpc.py:295-311, 85-88
- * with a FRESH decoder per frame (check-node state zeroed), which is what
- * evaluateCodeAtSingleTransmission does (ldpc.py:397).
+ * With keep_c2v == 0 every frame gets a FRESH decoder (check-node messages
+ * zeroed, checkNode.__init__ ldpc.py:121).  With keep_c2v != 0 the messages in
+ * c2v are kept from the previous frame, which is what happens when one
+ * reference decoder object decodes several frames: decoderSet resets only the
+ * variable nodes (ldpc.py:270-274; evaluateCode ldpc.py:356,377).
  *
  * c2v, v2c: scratch [E]; post: scratch [n].
  * sign_mode 0 = reference arithmetic (c2v sign = product of ALL signs times the
@@ -26,7 +29,7 @@
  * (-1)^degree, which is the textbook rule for the reference's bit polarity
  * (0 -> -1, ldpc.py:62-66); the two coincide for even check degree.
  */
-static void FN(decode_frame)(const oracle_graph *g, int sign_mode, int max_iters,
+static void FN(decode_frame)(const oracle_graph *g, int sign_mode, int keep_c2v, int max_iters,
                              const REAL *y, uint8_t *hard, int32_t *iters_out,
                              uint8_t *conv_out, REAL *soft_out,
                              REAL *c2v, REAL *v2c, REAL *post)
@@ -38,7 +41,8 @@ static void FN(decode_frame)(const oracle_graph *g, int sign_mode, int max_iters
     int ok;
 
     for (int c = 0; c < n; ++c) post[c] = y[c];
-    for (int e = 0; e < g->E; ++e) c2v[e] = (REAL)0;
+    if (!keep_c2v)                                      /* a re-used decoder keeps them, ldpc.py:270-274 */
+        for (int e = 0; e < g->E; ++e) c2v[e] = (REAL)0;
 
     ok = FN(syndrome_is_zero)(g, post);                 /* ldpc.py:327 */
     while (!ok && it < max_iters) {                      /* ldpc.py:332 */

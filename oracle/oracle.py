@@ -88,7 +88,7 @@ class Oracle:
         except Exception:
             pass
 
-    def _run(self, fn_name, dtype, y, max_iters, sign_mode, want_soft, threads, extra=()):
+    def _run(self, fn_name, dtype, y, max_iters, sign_mode, want_soft, threads, extra=(), state=None):
         y = np.ascontiguousarray(np.atleast_2d(y), dtype=dtype)
         F, n = y.shape
         assert n == self.n
@@ -101,16 +101,25 @@ class Oracle:
                 ctypes.c_int64(F), *extra, ctypes.c_void_p(y.ctypes.data),
                 ctypes.c_void_p(hard.ctypes.data), ctypes.c_void_p(iters.ctypes.data),
                 ctypes.c_void_p(conv.ctypes.data),
-                ctypes.c_void_p(soft.ctypes.data if want_soft else None), ctypes.c_int(threads))
+                ctypes.c_void_p(soft.ctypes.data if want_soft else None),
+                ctypes.c_void_p(state.ctypes.data if state is not None else None), ctypes.c_int(threads))
         if rc != 0:
             raise RuntimeError(f'{fn_name} failed: {rc}')
         return hard, iters, conv, soft
 
-    def minsum(self, y, max_iters=50, prec=64, sign_mode=0, want_soft=True, threads=1):
-        """-> (hard uint8 [F,n], iters int32 [F], converged uint8 [F], soft [F,n] or None)"""
-        if prec == 64:
-            return self._run('oracle_minsum_f64', np.float64, y, max_iters, sign_mode, want_soft, threads)
-        return self._run('oracle_minsum_f32', np.float32, y, max_iters, sign_mode, want_soft, threads)
+    def new_state(self, prec=64):
+        """Check-node messages of a freshly built decoder (all zero), for minsum(state=...)."""
+        return np.zeros(len(self.col_idx) + 1, np.float64 if prec == 64 else np.float32)
+
+    def minsum(self, y, max_iters=50, prec=64, sign_mode=0, want_soft=True, threads=1, state=None):
+        """-> (hard uint8 [F,n], iters int32 [F], converged uint8 [F], soft [F,n] or None).
+        state (from new_state, updated in place): decode the frames in order on ONE
+        re-used decoder instead of a fresh decoder per frame."""
+        dt = np.float64 if prec == 64 else np.float32
+        if state is not None:
+            assert state.dtype == dt and state.flags.c_contiguous
+        return self._run('oracle_minsum_f64' if prec == 64 else 'oracle_minsum_f32', dt, y, max_iters,
+                         sign_mode, want_soft, threads, state=state)
 
     def spa(self, y, llr_scale, max_iters=50, prec=64, sign_mode=0, want_soft=True, threads=1):
         """Sum-product (tanh rule) on LLR = llr_scale * y.  No counterpart in the reference."""

@@ -1,0 +1,139 @@
+"""GPU suite (-m gpu): the Python mirror of the reference's entry points."""
+import hashlib
+import importlib
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, build_code, golden_points
+
+pytestmark = pytest.mark.gpu
+
+
+def test_ldpcDecoder_decoderMainLoop_matches_reference():
+    from ldpc_amd import ldpc, fileHandler
+    H = fileHandler.nearEarthParity()                       # dense, as the reference passes it
+    pts = [p for p in golden_points('nearEarth')]
+    for pt in pts:
+        if pt['snr'] not in (0.0, 3.4, 4.5):
+            continue
+        for k in range(min(3, len(pt['iters']))):
+            y = pt['llr'][k].astype(np.float64)
+            dec = ldpc.ldpcDecoder(H)                       # the golden frames used a fresh decoder each
+            status, binv, soft, it = dec.decoderMainLoop(y, 50)
+            assert it == pt['iters'][k]
+            assert status == ('Codeword' if pt['conv'][k] else 'Not a codeword')
+            assert binv.dtype == np.int64 and soft.dtype == np.float64
+            assert np.array_equal(np.packbits(binv.astype(np.uint8), bitorder='little'), pt['hard'][k])
+            assert hashlib.sha256(np.ascontiguousarray(soft).tobytes()).digest() == bytes(pt['sha'][k])
+            st2, b2 = dec.isCodeword(soft)
+            assert st2 == status and np.array_equal(b2, binv)
+
+
+def test_reused_decoder_object_matches_reference():
+    """One decoder object, several frames: check-node messages carry over exactly as
+    in the reference (tests/golden/chained_decoder.npz)."""
+    from ldpc_amd import ldpc
+    g = np.load(os.path.join(GOLDEN, 'chained_decoder.npz'))
+    for name in ('nearEarth', 'wifi_5_6', 'rand_24_48'):
+        qc, H = build_code(name)
+        dec = ldpc.ldpcDecoder(H)
+        Y = g[f'{name}_llr']
+        for k in range(len(Y)):
+            status, binv, soft, it = dec.decoderMainLoop(Y[k].astype(np.float64), 50)
+            assert it == g[f'{name}_iters'][k], (name, k)
+            assert (status == 'Codeword') == bool(g[f'{name}_conv'][k])
+            assert np.array_equal(np.packbits(binv.astype(np.uint8), bitorder='little'), g[f'{name}_hard'][k])
+            assert hashlib.sha256(np.ascontiguousarray(soft).tobytes()).digest() == bytes(g[f'{name}_soft_sha256'][k])
+        # the same frames as one chained batch on a new object
+        dec2 = ldpc.ldpcDecoder(qc if qc is not None else H)
+        r = dec2.decodeBatch(Y.astype(np.float64), 50, wantSoft=True)
+        assert np.array_equal(r['iters'], g[f'{name}_iters'])
+        assert np.array_equal(r['hard_packed'], g[f'{name}_hard'])
+
+
+def test_evaluateCodeAtSingleTransmission_rows_match_reference():
+    """Same call as oracle/gen_golden.py made on the reference (fresh module state)."""
+    from ldpc_amd import ldpc, fileHandler
+    importlib.reload(ldpc)                                   # module PRNG back to its seed (ldpc.py:24)
+    g = np.load(os.path.join(GOLDEN, 'berstats_single_transmission.npz'))
+    bs = ldpc.evaluateCodeAtSingleTransmission(460101, [3.0, 3.2], 7154, 8176, 50, fileHandler.nearEarthParity())
+    rows = bs.getRawStats()
+    got = np.array([[float(x) for x in r[:8]] for r in rows])
+    assert np.array_equal(got, g['rows'])
+    assert [r[8] for r in rows] == [str(s) for s in g['status']]
+    with pytest.raises(AssertionError):
+        ldpc.evaluateCodeAtSingleTransmission(0, [3.0], 7154, 8176, 50, fileHandler.nearEarthParity())
+    with pytest.raises(AssertionError):
+        ldpc.evaluateCodeAtSingleTransmission(5, 3.0, 7154, 8176, 50, fileHandler.nearEarthParity())
+
+
+def test_evaluateCode_and_multiprocessing_mirror(oracle_mod):
+    from ldpc_amd import ldpc, codes
+    importlib.reload(ldpc)
+    H = codes.near_earth().to_dense()
+    orc = oracle_mod.Oracle(H)
+    bs = ldpc.evaluateCode(3, 17, [3.4, 4.0], 7154, 8176, 50, H)
+    rows = bs.getRawStats()
+    assert len(rows) == 6
+    # regenerate the frames the way the reference draws them (module PRNG, float64 noise)
+    prng = np.random.RandomState(7134066)
+    k = 0
+    state = orc.new_state(64)                # evaluateCode re-uses one decoder (ldpc.py:356, 377)
+    for snr in (3.4, 4.0):
+        sigma = np.sqrt(0.5 / 10 ** (snr / 10))
+        for _ in range(3):
+            noise = prng.normal(0, sigma, 8176)
+            y = -1.0 + noise
+            hard, iters, conv, _ = orc.minsum(y, 50, prec=64, state=state)
+            r = rows[k]
+            assert r[0] == snr and r[2] == sigma and r[3] == np.sqrt(np.sum(noise ** 2) / 8176)
+            assert r[4] == 0 and r[5] == hard.sum() and r[6] == iters[0]
+            assert r[8] == ('Codeword' if conv[0] else 'Not a codeword')
+            k += 1
+    bs2 = ldpc.testCodeUsingMultiprocessing(460101, [3.0, 3.2], 7154, 8176, 50, 4, H)
+    rows2 = bs2.getRawStats()
+    assert len(rows2) == 8 and rows2 == sorted(rows2)
+    assert all(r[4] == 1 and r[5] == 0 and r[8] == 'Codeword' for r in rows2)   # flipped first symbol is corrected
+
+
+def test_evaluateCodeCuda_matches_oracle_on_host_seeded_frames(oracle_mod):
+    from ldpc_amd import ldpcHIP, codes
+    H = codes.near_earth().to_dense().astype(np.int32)
+    orc = oracle_mod.Oracle(H)
+    snrs = [3.2, 3.6]
+    nTx = 6
+    bs = ldpcHIP.evaluateCodeCuda(460101, snrs, 50, H, nTx)
+    rows = bs.getRawStats()
+    assert len(rows) == 12
+    prng = np.random.RandomState(460101)
+    k = 0
+    for snr in snrs:
+        sigma = np.sqrt(0.5 / 10 ** (snr / 10))
+        for _ in range(nTx):
+            noise = np.float32(prng.normal(0, sigma, 8176))
+            y = np.float32(-1) + noise
+            hard, iters, conv, _ = orc.minsum(y, 50, prec=32)
+            r = rows[k]
+            assert r[0] == snr and r[2] == sigma
+            assert r[4] == np.count_nonzero(y > 0) and r[5] == hard.sum() and r[6] == iters[0] and r[7] == 50
+            k += 1
+    # wrapper: nTx // devices frames per device, device d seeded with seeds[d]
+    seeds = [460101, 7]
+    bw = ldpcHIP.evaluateCodeCudaWrapper(seeds, snrs, 50, H, 12, 'None', 2)
+    rw = bw.getRawStats()
+    assert len(rw) == 2 * 2 * 6
+    assert [tuple(r[:8]) for r in rw[:12]] == [tuple(r[:8]) for r in rows]
+    st, status = ldpcHIP.testNearEarth(8)
+    assert status == 'OK'
+
+
+def test_device_rng_evaluation_statistics():
+    from ldpc_amd import ldpcHIP, codes
+    bs = ldpcHIP.evaluateCodeCuda(5, [3.0, 3.4, 3.8], 50, codes.near_earth(), 200, deviceRng=True)
+    scSnr, scBer, scItr, snrAxis, avgSnr, ber, _ = bs.getStatsV2()
+    assert len(scSnr) == 600 and np.allclose(avgSnr, snrAxis, atol=0.02)
+    # anchors embedded in the reference (common.py:113-114; rewardInvestigation.ipynb:64):
+    # BER ~0.02 at 3.0 dB, dropping to 0 by 3.4-3.6 dB
+    assert 0.012 < ber[0] < 0.03 and ber[1] < 0.004 and ber[2] == 0

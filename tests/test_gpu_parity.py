@@ -1,0 +1,267 @@
+"""GPU suite (-m gpu): the HIP path, called through the C ABI, against
+  * the golden vectors of the reference (float64 arithmetic: bit-exact hard decisions,
+    iteration counts, status AND soft vectors),
+  * the CPU oracle in float32 (bit-exact as well),
+  * size-independent properties at bench scale.
+"""
+import hashlib
+
+import numpy as np
+import pytest
+
+from conftest import ALL_CODES, build_code, golden_points, make_llrs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def engines():
+    import ldpc_amd
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            qc, H = build_code(name)
+            cache[name] = ldpc_amd.Decoder(qc if qc is not None else H)
+        return cache[name]
+    yield get
+    for e in cache.values():
+        e.close()
+
+
+@pytest.mark.parametrize('name', ALL_CODES)
+def test_f64_bit_exact_against_reference_golden(engines, name):
+    eng = engines(name)
+    for pt in golden_points(name):
+        r = eng.decode(pt['llr'], pt['max_iters'], prec=64, want_soft=True)
+        assert np.array_equal(r['iters'], pt['iters']), (name, pt['seed'], r['iters'], pt['iters'])
+        assert np.array_equal(r['converged'], pt['conv'])
+        assert np.array_equal(r['hard_packed'], pt['hard'])
+        assert np.array_equal(r['ones'], r['hard'].sum(1))
+        for k in range(len(pt['iters'])):
+            if pt['iters'][k] == 0:
+                continue    # the host mirror returns the input itself for 0 iterations
+            assert hashlib.sha256(r['soft'][k].tobytes()).digest() == bytes(pt['sha'][k]), (name, pt['seed'], k)
+
+
+@pytest.mark.parametrize('name', ALL_CODES)
+def test_f32_bit_exact_against_oracle(engines, oracle_mod, name):
+    eng = engines(name)
+    _, H = build_code(name)
+    orc = oracle_mod.Oracle(H)
+    for pt in golden_points(name):
+        Y = pt['llr'][:16]
+        hard, iters, conv, soft = orc.minsum(Y, 50, prec=32, threads=8)
+        r = eng.decode(Y, 50, prec=32, want_soft=True)
+        assert np.array_equal(r['iters'], iters), (name, pt['seed'])
+        assert np.array_equal(r['converged'], conv)
+        assert np.array_equal(r['hard'], hard)
+        assert np.array_equal(r['soft'], soft)
+
+
+@pytest.mark.parametrize('name', ['nearEarth_mut_w3', 'nearEarth_mut_w7', 'wifi_5_6', 'rand_24_48'])
+def test_corrected_sign_mode_against_oracle(engines, oracle_mod, name):
+    """Odd check degrees: opt-in sign rule (-1)^degree, both arithmetic widths."""
+    eng = engines(name)
+    _, H = build_code(name)
+    orc = oracle_mod.Oracle(H)
+    pt = [p for p in golden_points(name) if not p['special']][0]
+    Y = pt['llr'][:8]
+    for prec, dt in ((64, np.float64), (32, np.float32)):
+        hard, iters, conv, soft = orc.minsum(Y.astype(dt), 50, prec=prec, sign_mode=1, threads=8)
+        r = eng.decode(Y, 50, prec=prec, sign_mode=1, want_soft=True)
+        assert np.array_equal(r['iters'], iters) and np.array_equal(r['converged'], conv)
+        assert np.array_equal(r['hard'], hard) and np.array_equal(r['soft'], soft)
+    if name == 'wifi_5_6':
+        # with the textbook sign rule the WiFi code does decode at 6 dB
+        pt6 = [p for p in golden_points(name) if p['snr'] == 6.0][0]
+        r = eng.decode(pt6['llr'], 50, prec=64, sign_mode=1)
+        assert r['converged'].all() and r['ones'].sum() == 0
+
+
+@pytest.mark.parametrize('prec', [64, 32])
+def test_chained_decoder_against_oracle(engines, oracle_mod, prec):
+    """ldpc_decode_chained: state carried across frames AND across calls; reset works."""
+    import ldpc_amd
+    dt = np.float64 if prec == 64 else np.float32
+    for name in ('nearEarth', 'nearEarth_mut_w7', 'wifi_5_6', 'rand_24_48'):
+        qc, H = build_code(name)
+        orc = oracle_mod.Oracle(H)
+        pts = [p for p in golden_points(name) if not p['special']]
+        Y = np.concatenate([pts[-1]['llr'][:5], pts[0]['llr'][:3]])
+        state = orc.new_state(prec)
+        hard, iters, conv, soft = orc.minsum(Y.astype(dt), 50, prec=prec, state=state)
+        with ldpc_amd.Decoder(qc if qc is not None else H) as eng:
+            r1 = eng.decode(Y[:3], 50, prec=prec, want_soft=True, chained=True)
+            r2 = eng.decode(Y[3:], 50, prec=prec, want_soft=True, chained=True)
+            got_it = np.concatenate([r1['iters'], r2['iters']])
+            got_soft = np.concatenate([r1['soft'], r2['soft']])
+            assert np.array_equal(got_it, iters), (name, got_it, iters)
+            assert np.array_equal(got_soft, soft)
+            assert np.array_equal(np.concatenate([r1['hard'], r2['hard']]), hard)
+            eng.reset_state()
+            r3 = eng.decode(Y[:3], 50, prec=prec, want_soft=True, chained=True)
+            assert np.array_equal(r3['iters'], iters[:3]) and np.array_equal(r3['soft'], soft[:3])
+            # the unchained entry point is unaffected by the state
+            f = orc.minsum(Y.astype(dt), 50, prec=prec)
+            r4 = eng.decode(Y, 50, prec=prec, want_soft=True)
+            assert np.array_equal(r4['iters'], f[1]) and np.array_equal(r4['soft'], f[3])
+
+
+def test_float64_channel_values(engines, oracle_mod):
+    """float64 inputs that are not float32-representable (what ldpc.addAWGN produces)."""
+    eng = engines('nearEarth')
+    _, H = build_code('nearEarth')
+    orc = oracle_mod.Oracle(H)
+    prng = np.random.RandomState(7134066)
+    sigma = np.sqrt(0.5 / 10 ** 0.34)
+    Y = -1.0 + prng.normal(0, sigma, (6, 8176))
+    hard, iters, conv, soft = orc.minsum(Y, 50, prec=64, threads=6)
+    r = eng.decode(Y, 50, prec=64, want_soft=True)
+    assert np.array_equal(r['iters'], iters) and np.array_equal(r['hard'], hard)
+    assert np.array_equal(r['soft'], soft)
+
+
+def test_edge_cases(engines, oracle_mod):
+    eng = engines('nearEarth')
+    n = eng.n
+    # empty batch
+    r = eng.decode(np.zeros((0, n), np.float32), 50, prec=32)
+    assert r['iters'].shape == (0,) and r['hard'].shape == (0, n)
+    # iteration budget 0 and 1
+    pt = [p for p in golden_points('nearEarth') if p['snr'] == 3.4 and not p['special']][0]
+    Y = pt['llr'][:5]
+    _, H = build_code('nearEarth')
+    orc = oracle_mod.Oracle(H)
+    for budget in (0, 1, 3):
+        hard, iters, conv, soft = orc.minsum(Y.astype(np.float64), budget, prec=64)
+        r = eng.decode(Y, budget, prec=64, want_soft=True)
+        assert np.array_equal(r['iters'], iters) and np.array_equal(r['converged'], conv)
+        assert np.array_equal(r['hard'], hard) and np.array_equal(r['soft'], soft)
+    # negative zero and exact zero inputs decide 0
+    y = np.full((1, n), -1.0, np.float32)
+    y[0, :4] = [-0.0, 0.0, -0.0, 0.0]
+    hard, iters, conv, _ = orc.minsum(y.astype(np.float64), 50, prec=64)
+    r = eng.decode(y, 50, prec=64)
+    assert np.array_equal(r['hard'], hard) and r['iters'][0] == iters[0] == 0
+    # erasure burst (zeros) in a noisy frame: the decoder has to fill it in
+    y = pt['llr'][:2].copy()
+    y[:, 100:140] = 0.0
+    hard, iters, conv, soft = orc.minsum(y.astype(np.float64), 50, prec=64)
+    r = eng.decode(y, 50, prec=64, want_soft=True)
+    assert np.array_equal(r['iters'], iters) and np.array_equal(r['soft'], soft)
+
+
+def test_ragged_batches_on_packed_frames(engines, oracle_mod):
+    """WiFi frames are packed several to a workgroup; batch sizes that do not fill the last one."""
+    eng = engines('wifi_5_6')
+    _, H = build_code('wifi_5_6')
+    orc = oracle_mod.Oracle(H)
+    info = eng.launch_info(prec=32)
+    assert info['frames_per_wg'] >= 2
+    Y = np.concatenate([make_llrs(11, 8.0, 1944, 9), make_llrs(12, 5.0, 1944, 4)])
+    hard, iters, conv, soft = orc.minsum(Y, 50, prec=32, sign_mode=1, threads=8)
+    for F in (1, 2, 3, 5, 13):
+        r = eng.decode(Y[:F], 50, prec=32, sign_mode=1, want_soft=True)
+        assert np.array_equal(r['iters'], iters[:F]) and np.array_equal(r['hard'], hard[:F])
+        assert np.array_equal(r['soft'], soft[:F])
+    assert len(set(iters.tolist())) > 2      # frames of one workgroup stop at different iterations
+
+
+def test_device_entry_points_and_channel(engines):
+    import torch
+    eng = engines('nearEarth')
+    n, F = eng.n, 512
+    dev = torch.device('cuda:0')
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    llr = torch.empty((F, n), dtype=torch.float32, device=dev)
+    sig = torch.empty(F, dtype=torch.float32, device=dev)
+    unc = torch.empty(F, dtype=torch.int32, device=dev)
+    eng.channel_awgn_device(llr, F, 3.5, seed=1234, first_frame=0, d_sigma_hat=sig, d_uncoded=unc)
+    # same frames again, shifted window: counter-based noise does not depend on the batch
+    llr2 = torch.empty((F // 2, n), dtype=torch.float32, device=dev)
+    eng.channel_awgn_device(llr2, F // 2, 3.5, seed=1234, first_frame=F // 2)
+    torch.cuda.synchronize()
+    assert torch.equal(llr[F // 2:], llr2)
+    y = llr.cpu().numpy().astype(np.float64)
+    sigma = np.sqrt(0.5 / 10 ** 0.35)
+    noise = y + 1.0
+    assert abs(noise.mean()) < 4 * sigma / np.sqrt(noise.size)
+    assert abs(noise.std() / sigma - 1) < 5e-3
+    z = noise / sigma
+    assert abs((z ** 4).mean() - 3.0) < 0.02 and abs((z ** 3).mean()) < 0.01
+    assert np.allclose(sig.cpu().numpy(), np.sqrt((noise ** 2).mean(1)), rtol=1e-5)
+    assert np.array_equal(unc.cpu().numpy(), (y > 0).sum(1))
+    # decode on the device, compare with the host entry point on the same values
+    hard = torch.zeros((F, eng.nbytes), dtype=torch.uint8, device=dev)
+    iters = torch.zeros(F, dtype=torch.int32, device=dev)
+    conv = torch.zeros(F, dtype=torch.uint8, device=dev)
+    ones = torch.zeros(F, dtype=torch.int32, device=dev)
+    eng.decode_device(llr, F, 50, prec=32, d_hard=hard, d_iters=iters, d_conv=conv, d_ones=ones)
+    torch.cuda.synchronize()
+    eng.set_stream(None)
+    r = eng.decode(llr.cpu().numpy(), 50, prec=32)
+    assert np.array_equal(r['iters'], iters.cpu().numpy())
+    assert np.array_equal(r['hard_packed'], hard.cpu().numpy())
+    assert np.array_equal(r['ones'], ones.cpu().numpy())
+    assert conv.cpu().numpy().mean() > 0.95          # 3.5 dB: essentially every frame decodes
+
+
+def test_sweep_driver_counts(engines):
+    eng = engines('nearEarth')
+    snr = [3.0, 3.5, 4.5]
+    F = 256
+    cnt, pf = eng.eval_awgn(snr, F, seed=99, max_iters=50, prec=32, per_frame=True)
+    assert cnt.shape == (3, 6) and pf.shape == (3, F, 4)
+    assert np.all(cnt[:, 0] == F)
+    assert np.array_equal(cnt[:, 2], pf[:, :, 2].sum(1).astype(np.uint64))
+    assert np.array_equal(cnt[:, 3], pf[:, :, 3].sum(1).astype(np.uint64))
+    assert np.array_equal(cnt[:, 4], pf[:, :, 1].sum(1).astype(np.uint64))
+    assert np.array_equal(cnt[:, 1], (pf[:, :, 2] > 0).sum(1).astype(np.uint64))
+    mean_it = cnt[:, 3] / F
+    assert mean_it[0] > 30 and 4 < mean_it[1] < 12 and mean_it[2] < 4      # cf. reference runs: 47.8 / 7.6 / 2.6
+    assert cnt[1, 1] <= 2 and cnt[2, 1] == 0
+    # uncoded BER ~ Q(1/sigma)
+    from math import erfc, sqrt
+    for k, s in enumerate(snr):
+        sigma = sqrt(0.5 / 10 ** (s / 10))
+        q = 0.5 * erfc(1 / sigma / sqrt(2))
+        assert abs(cnt[k, 4] / (F * 8176) / q - 1) < 0.03
+    # splitting the frame range reproduces the same totals (counter-based noise)
+    c1, _ = eng.eval_awgn(snr, F // 2, seed=99, first_frame=0, prec=32)
+    c2, _ = eng.eval_awgn(snr, F // 2, seed=99, first_frame=F // 2, prec=32)
+    assert np.array_equal(c1 + c2, cnt)
+
+
+def test_bench_scale_properties(engines):
+    """At bench sizes there is no oracle run; check invariants of the outputs instead."""
+    import torch
+    eng = engines('nearEarth')
+    n, F = eng.n, 20000
+    dev = torch.device('cuda:0')
+    llr = torch.empty((F, n), dtype=torch.float32, device=dev)
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    eng.channel_awgn_device(llr, F, 3.5, seed=7, first_frame=0)
+    hard = torch.zeros((F, eng.nbytes), dtype=torch.uint8, device=dev)
+    iters = torch.zeros(F, dtype=torch.int32, device=dev)
+    conv = torch.zeros(F, dtype=torch.uint8, device=dev)
+    ones = torch.zeros(F, dtype=torch.int32, device=dev)
+    eng.decode_device(llr, F, 50, prec=32, d_hard=hard, d_iters=iters, d_conv=conv, d_ones=ones)
+    torch.cuda.synchronize()
+    it, cv, on = iters.cpu().numpy(), conv.cpu().numpy(), ones.cpu().numpy()
+    hb = np.unpackbits(hard.cpu().numpy(), axis=1, bitorder='little')[:, :n]
+    assert np.array_equal(on, hb.sum(1))
+    H = eng.qc.to_dense().astype(np.uint8)
+    # status is exactly "syndrome of the returned hard decision is zero"
+    sub = np.concatenate([np.flatnonzero(on)[:50], np.arange(200)])
+    synd = (hb[sub].astype(np.int32) @ H.T.astype(np.int32)) % 2
+    assert np.array_equal(synd.any(1) == 0, cv[sub] == 1)
+    assert np.all(it[cv == 0] == 50) and np.all(it[cv == 1] <= 50)
+    assert cv.mean() > 0.995 and 5 < it.mean() < 10
+    # idempotence: decoding again gives the same answer; order of frames does not matter
+    iters2 = torch.zeros(F, dtype=torch.int32, device=dev)
+    perm = torch.randperm(F, device=dev)
+    eng.decode_device(llr[perm].contiguous(), F, 50, prec=32, d_iters=iters2)
+    torch.cuda.synchronize()
+    eng.set_stream(None)
+    assert torch.equal(iters2, iters[perm])

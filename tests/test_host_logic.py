@@ -1,0 +1,146 @@
+"""CPU suite: host-side logic of the package and the C-ABI surface (no compute calls)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT, build_code
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    from ldpc_amd import _lib
+    L = _lib.load()
+    header = open(os.path.join(ROOT, 'include', 'ldpc_hip.h')).read()
+    declared = set(re.findall(r'\b(ldpc_[a-z_0-9]+)\s*\(', header))
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    for name in declared:
+        assert hasattr(L, name), name
+    assert isinstance(L.ldpc_last_error(), bytes)
+    assert L.ldpc_device_count() >= 0
+
+
+def test_no_silent_cpu_fallback():
+    """Without a HIP device, building a decoder must raise; nothing decodes on the CPU."""
+    import ldpc_amd
+    from ldpc_amd import codes
+    if ldpc_amd.device_count() > 0:
+        pytest.skip('a HIP device is visible')
+    with pytest.raises(ldpc_amd.LdpcHipError):
+        ldpc_amd.Decoder(codes.near_earth())
+    from ldpc_amd import ldpc
+    with pytest.raises(ldpc_amd.LdpcHipError):
+        ldpc.ldpcDecoder(codes.near_earth())
+
+
+def test_argument_errors_do_not_need_a_device():
+    from ldpc_amd import _lib
+    L = _lib.load()
+    h = ctypes.c_void_p()
+    ptr = np.array([0, 1], np.int32)
+    sh = np.array([7], np.int32)
+    assert L.ldpc_create_qc(0, 4, 1, 1, ptr.ctypes.data, sh.ctypes.data, ctypes.byref(h)) == -1
+    assert b'shift' in L.ldpc_last_error()
+    assert L.ldpc_create_qc(0, 0, 1, 1, ptr.ctypes.data, sh.ctypes.data, ctypes.byref(h)) == -1
+    assert L.ldpc_create_qc(0, 511, 3, 16, np.zeros(49, np.int32).ctypes.data, None, ctypes.byref(h)) == -3
+    rp = np.array([0, 2, 1], np.int32)
+    assert L.ldpc_create_csr(0, 2, 4, rp.ctypes.data, sh.ctypes.data, ctypes.byref(h)) == -1
+    assert L.ldpc_decode(None, 0, 32, 0, 50, 1, None, 32, None, None, None, None, None) == -1
+    assert L.ldpc_sync(None) == -1
+
+
+def test_code_tables_and_conversions():
+    from ldpc_amd import codes, fileHandler, wifiMatrices
+    ne = codes.near_earth()
+    assert (ne.Z, ne.mb, ne.nb, ne.m, ne.n, ne.nnz) == (511, 2, 16, 1022, 8176, 32704)
+    assert ne.row_degrees() == [32, 32] and set(ne.col_degrees()) == {4}
+    H = ne.to_dense()
+    # fileHandler.py:137-142 convention, spot values of the reference's matrix
+    assert set(np.flatnonzero(H[0, :511])) == {0, 176}
+    assert set(np.flatnonzero(H[1, :511])) == {1, 177}
+    assert set(np.flatnonzero(H[511, :511])) == {99, 471}
+    assert np.array_equal(fileHandler.nearEarthParity(), H)
+    back = codes.detect_qc(H)
+    assert back.Z == 511 and back.blocks == ne.blocks
+    w = codes.wifi_1944_r56()
+    Hw = wifiMatrices.getWifiParityMatrix()
+    assert Hw.shape == (324, 1944) and int(Hw.sum()) == 6399
+    assert sorted(set(Hw.sum(1))) == [19, 20] and sorted(set(Hw.sum(0))) == [2, 3, 4]
+    assert codes.detect_qc(Hw).blocks == w.blocks
+    z = codes.near_earth_zeroed(1, 3)
+    assert z.nnz == 32704 - 2 * 511 and z.blocks[1][3] == ()
+    # a matrix that is not block-circulant goes to CSR
+    _, Hr = build_code('rand_24_48')
+    assert codes.detect_qc(Hr) is None
+    m, n, rp, ci = codes.dense_to_csr(Hr)
+    assert (m, n) == (24, 48) and rp[-1] == Hr.sum()
+    for r in range(m):
+        assert np.array_equal(ci[rp[r]:rp[r + 1]], np.flatnonzero(Hr[r]))
+    with pytest.raises(ValueError):
+        codes.QCCode(5, [[(1, 1)]])
+    with pytest.raises(ValueError):
+        codes.QCCode(5, [[(5,)]])
+
+
+def test_hot_position_file_round_trip(tmp_path):
+    from ldpc_amd import codes, fileHandler
+    ne = codes.near_earth()
+    p = tmp_path / 'parity.txt'
+    with open(p, 'w') as fid:
+        for row in ne.blocks:
+            for blk in row:
+                fid.write(', '.join(str(s) for s in blk) + '\n')
+    H = fileHandler.readMatrixFromFile(str(p), 1022, 8176, 511, True, False, False)
+    assert H.dtype == np.int32 and np.array_equal(H, ne.to_dense())
+    assert np.array_equal(fileHandler.hotLocationsToCirculant([0, 3], 5),
+                          np.array([[1, 0, 0, 1, 0], [0, 1, 0, 0, 1], [1, 0, 1, 0, 0],
+                                    [0, 1, 0, 1, 0], [0, 0, 1, 0, 1]]))
+    with pytest.raises(NotImplementedError):
+        fileHandler.readMatrixFromFile(str(p), 7154, 8176, 511, True, True, True)
+
+
+def test_ber_statistics_matches_reference_rows():
+    """Rows and getStatsV2 of the reference's evaluateCodeAtSingleTransmission run
+    (tests/golden/berstats_single_transmission.npz) rebuilt through the mirror class."""
+    from ldpc_amd import common
+    g = np.load(os.path.join(GOLDEN, 'berstats_single_transmission.npz'))
+    rows, status = g['rows'], g['status']
+    bs = common.berStatistics()
+    for r, st in zip(rows, status):
+        snr, snrAct, sigma, sigmaAct, unc, dec, it, mx = r
+        bs.addEntry(snr, sigma, sigmaAct, unc, dec, it, mx, str(st))
+    got = np.array([[float(x) for x in row[:8]] for row in bs.getRawStats()])
+    assert np.array_equal(got, rows)
+    v2 = bs.getStatsV2()
+    for i, a in enumerate(v2):
+        assert np.array_equal(np.asarray(a), g[f'v2_{i}'], equal_nan=True), i
+    assert np.all(v2[6] == 0)          # the reference never accumulates iterations (common.py:219)
+    assert np.all(bs.getStatsV2(fixAverageIterations=True)[6] == rows[:, 6])
+    u = bs.union(bs)
+    assert len(u.stats) == 2 * len(bs.stats) and u.stats == sorted(bs.stats + bs.stats)
+    a = bs.add(bs)
+    assert a.stats == bs.stats + bs.stats and a.snrAxis == bs.snrAxis
+
+
+def test_primitives():
+    from ldpc_amd import ldpc
+    v = np.array([0, 1, 1, 0, 1])
+    mod = ldpc.modulate(v, 5)
+    assert mod.dtype == np.float64 and np.array_equal(mod, [-1, 1, 1, -1, 1])
+    assert np.array_equal(ldpc.slicer(np.array([-0.1, 0.0, 2.0, -0.0, 1e-300]), 5), [0, 0, 1, 0, 1])
+    assert ldpc.testModulationAndSlicingRoundTrip() == 'OK'
+    prng = np.random.RandomState(5)
+    noisy, sigma, sigmaActual = ldpc.addAWGN(mod, 5, 3.0, prng)
+    ref = np.random.RandomState(5).normal(0, np.sqrt(0.5 / 10 ** 0.3), 5)
+    assert np.array_equal(noisy, mod + ref) and sigma == np.sqrt(0.5 / 10 ** 0.3)
+    assert sigmaActual == np.sqrt(np.sum(ref ** 2) / 5)
+
+
+def test_recursive_linear_fit():
+    from ldpc_amd import common
+    x = np.array([3.0, 3.2, 3.4, 3.6, 3.8])
+    y = np.array([0.02, 0.012, 0.004, 0.0, 0.0])
+    snr, ber, p, trend, itr = common.recursiveLinearFit(x, y)
+    assert itr == 10 and len(snr) == len(ber) and np.all(trend(snr) > 0)
+    assert np.allclose(p, np.polyfit(snr, ber, 1))

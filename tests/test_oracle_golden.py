@@ -25,6 +25,31 @@ def test_oracle_f64_matches_reference_bit_for_bit(oracle_mod, name):
     assert n_frames > 0
 
 
+def test_oracle_reused_decoder_matches_reference(oracle_mod):
+    """Frames decoded in a row by ONE reference decoder object (stale check-node
+    messages, ldpc.py:270-274): tests/golden/chained_decoder.npz."""
+    import os
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, 'chained_decoder.npz'))
+    for name in ('nearEarth', 'wifi_5_6', 'rand_24_48'):
+        _, H = build_code(name)
+        orc = oracle_mod.Oracle(H)
+        state = orc.new_state(64)
+        Y = g[f'{name}_llr'].astype(np.float64)
+        half = len(Y) // 2
+        res = [orc.minsum(Y[:half], 50, prec=64, state=state), orc.minsum(Y[half:], 50, prec=64, state=state)]
+        iters = np.concatenate([r[1] for r in res])
+        hard = np.concatenate([r[0] for r in res])
+        soft = np.concatenate([r[3] for r in res])
+        assert np.array_equal(iters, g[f'{name}_iters']), name
+        assert np.array_equal(np.packbits(hard, axis=1, bitorder='little'), g[f'{name}_hard'])
+        for k in range(len(Y)):
+            assert hashlib.sha256(soft[k].tobytes()).digest() == bytes(g[f'{name}_soft_sha256'][k])
+        # and it differs from independent decoding (otherwise the fixture pins nothing)
+        fresh = orc.minsum(Y, 50, prec=64)
+        assert name == 'wifi_5_6' or not np.array_equal(fresh[1], iters) or not np.array_equal(fresh[3], soft)
+
+
 def test_numpy_restatement_agrees_with_c_oracle(oracle_mod):
     _, H = build_code('rand_24_48')
     orc = oracle_mod.Oracle(H)
