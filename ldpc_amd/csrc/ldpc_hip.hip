@@ -21,6 +21,7 @@
 #include <stdarg.h>
 #include <string.h>
 #include <math.h>
+#include <stdlib.h>
 #include <vector>
 #include <algorithm>
 #include <new>
@@ -112,6 +113,22 @@ __device__ __forceinline__ T load_llr(const void *llr, int is_f64, int64_t idx)
 {
     return is_f64 ? T(reinterpret_cast<const double *>(llr)[idx])
                   : T(reinterpret_cast<const float *>(llr)[idx]);
+}
+// CPT channel values of one frame, element base + q*stride (q = 0..CPT-1).  The float32 /
+// float64 decision is taken ONCE around the unrolled loop, so the loads are issued back to
+// back; a per-element decision makes the compiler branch and wait for every single load.
+template <typename T, int CPT>
+__device__ __forceinline__ void load_llr_strided(const void *llr, int is_f64, int64_t base, int stride, T (&out)[CPT])
+{
+    if (is_f64) {
+        const double *p = reinterpret_cast<const double *>(llr) + base;
+#pragma unroll
+        for (int q = 0; q < CPT; ++q) out[q] = T(p[(int64_t)q * stride]);
+    } else {
+        const float *p = reinterpret_cast<const float *>(llr) + base;
+#pragma unroll
+        for (int q = 0; q < CPT; ++q) out[q] = T(p[(int64_t)q * stride]);
+    }
 }
 __device__ __forceinline__ float t_inf(float) { return __uint_as_float(0x7f800000u); }
 __device__ __forceinline__ double t_inf(double) { return __hiloint2double(0x7ff00000, 0); }
@@ -383,6 +400,9 @@ qc_minsum_kernel(const QcTables tb, const DecodeArgs a)
     }
 }
 
+#include "qc_regular.h"
+#include "qc_planes.h"
+
 // ---------------------------------------------------------------- CSR min-sum kernel
 //
 // Arbitrary sparse H.  One 256-thread workgroup per frame; posteriors and the
@@ -643,6 +663,11 @@ struct ldpc_handle {
     // QC
     QcTables qc{};
     int cols_per_thread = 0;
+    // regular fast path (every non-empty block has the same number of shifts)
+    bool is_regular = false;
+    bool reg_holes = false;
+    int reg_w = 0;
+    RegTables reg{};
     // CSR
     CsrTables csr{};
     std::vector<void *> tables;   // device allocations owned by the handle
@@ -769,6 +794,37 @@ extern "C" int ldpc_create_qc(int device, int Z, int mb, int nb, const int32_t *
     h->m = mb * Z; h->n = nb * Z; h->E = blk_ptr[nblk] * Z; h->max_row_deg = max_deg;
     h->cols_per_thread = (nb + mb - 1) / mb;
     h->qc.Z = Z; h->qc.Zp = Zp; h->qc.mb = mb; h->qc.nb = nb; h->qc.m = h->m; h->qc.n = h->n;
+    // regular structure?  (same weight W in {1,2} for every non-empty block, and a block
+    // geometry one of the unrolled instantiations covers)
+    {
+        int w = 0;
+        bool regular = true, holes = false;
+        for (int k = 0; k < nblk && regular; ++k) {
+            const int wk = blk_ptr[k + 1] - blk_ptr[k];
+            if (wk == 0) { holes = true; continue; }
+            if (w == 0) w = wk;
+            if (wk != w) regular = false;
+        }
+        const bool geom = (mb == 2 && nb == 16 && w == 2) || (mb == 4 && nb == 24 && w == 1);
+        const char *force = getenv("LDPC_HIP_FORCE_GENERIC");
+        if (regular && geom && !(force && force[0] == '1')) {
+            std::vector<int32_t> sh((size_t)mb * nb * w, 0);
+            for (int b = 0; b < mb; ++b)
+                for (int j = 0; j < nb; ++j) {
+                    const int k0 = blk_ptr[b * nb + j], k1 = blk_ptr[b * nb + j + 1];
+                    if (k1 == k0) continue;
+                    std::vector<int32_t> v(shifts + k0, shifts + k1);
+                    std::sort(v.begin(), v.end());
+                    for (int k = 0; k < w; ++k) sh[((size_t)b * nb + j) * w + k] = v[k];
+                    h->reg.row_mask[b] |= 1u << j;
+                }
+            h->is_regular = true;
+            h->reg_holes = holes;
+            h->reg_w = w;
+            h->reg.Z = Z; h->reg.Zp = Zp; h->reg.nb = nb; h->reg.n = h->n;
+            if ((rc = upload(h, sh, &h->reg.shifts))) { ldpc_destroy(h); return rc; }
+        }
+    }
     if ((rc = upload(h, row_ptr, &h->qc.row_ptr)) || (rc = upload(h, row_ent, &h->qc.row_ent)) ||
         (rc = upload(h, col_ptr, &h->qc.col_ptr)) || (rc = upload(h, col_grp, &h->qc.col_grp)) ||
         (rc = upload(h, col_ent, &h->qc.col_ent))) {
@@ -890,6 +946,46 @@ static int qc_select(const ldpc_handle *h, bool chained, Launch *L)
     return qc_pick<T, S64, 32, 1>(h, L);
 }
 
+template <typename T, int MB, int W, int CPT, int FPW>
+static int reg_pick(const ldpc_handle *h, Launch *L)
+{
+    L->fn = h->reg_holes ? reinterpret_cast<const void *>(&qc_regular_kernel<T, MB, W, CPT, FPW, true>)
+                         : reinterpret_cast<const void *>(&qc_regular_kernel<T, MB, W, CPT, FPW, false>);
+    L->block = FPW * MB * h->reg.Zp;
+    L->fpw = FPW;
+    const size_t slots = (size_t)FPW * MB * h->reg.Zp;
+    size_t b = (((size_t)FPW * h->reg.n * sizeof(T)) + 15) & ~(size_t)15;
+    b += slots * RegState<T>::BYTES + 3 * FPW * sizeof(int);
+    L->lds = (b + 15) & ~(size_t)15;
+    return 0;
+}
+
+// float32 NearEarth-shaped codes: explicit messages in LDS (qc_planes.h)
+static bool planes_applies(const ldpc_handle *h, int prec, bool chained)
+{
+    const char *off = getenv("LDPC_HIP_NO_PLANES");
+    return h->is_regular && prec == 32 && !chained && h->qc.mb == 2 && h->qc.nb == 16 && h->reg_w == 2 &&
+           h->qc.Z == 511 && (size_t)PlanesGeom<511, 8>::LDS_BYTES <= h->lds_max && !(off && off[0] == '1');
+}
+
+static int planes_pick(const ldpc_handle *h, Launch *L)
+{
+    L->fn = h->reg_holes ? reinterpret_cast<const void *>(&qc_planes_kernel<511, 8, true>)
+                         : reinterpret_cast<const void *>(&qc_planes_kernel<511, 8, false>);
+    L->block = 2 * PlanesGeom<511, 8>::ZP;
+    L->fpw = 1;
+    L->lds = PlanesGeom<511, 8>::LDS_BYTES;
+    return 0;
+}
+
+template <typename T>
+static int reg_select(const ldpc_handle *h, bool chained, Launch *L)
+{
+    if (h->qc.mb == 2) return reg_pick<T, 2, 2, 8, 1>(h, L);
+    if (chained) return reg_pick<T, 4, 1, 6, 1>(h, L);
+    return reg_pick<T, 4, 1, 6, 2>(h, L);
+}
+
 static size_t csr_ws_stride(const ldpc_handle *h, int prec)
 {
     const size_t ts = prec == 64 ? 8 : 4;
@@ -908,7 +1004,9 @@ static int select_launch(ldpc_handle *h, int algo, int prec, int64_t n_frames, b
     if (h->is_qc) {
         const bool s64 = h->max_row_deg > 32;
         int rc;
-        if (prec == 32) rc = s64 ? qc_select<float, true>(h, chained, L) : qc_select<float, false>(h, chained, L);
+        if (planes_applies(h, prec, chained)) rc = planes_pick(h, L);
+        else if (h->is_regular) rc = prec == 32 ? reg_select<float>(h, chained, L) : reg_select<double>(h, chained, L);
+        else if (prec == 32) rc = s64 ? qc_select<float, true>(h, chained, L) : qc_select<float, false>(h, chained, L);
         else            rc = s64 ? qc_select<double, true>(h, chained, L) : qc_select<double, false>(h, chained, L);
         if (rc) return rc;
         if (L->lds > h->lds_max)
@@ -936,9 +1034,8 @@ static int select_launch(ldpc_handle *h, int algo, int prec, int64_t n_frames, b
 static size_t chain_bytes(const ldpc_handle *h, int prec)
 {
     if (!h->is_qc) return 0;   // CSR: the whole workspace slice persists (csr_ws_stride)
-    const size_t slots = (size_t)h->qc.mb * h->qc.Zp;
-    const size_t ts = prec == 64 ? 8 : 4;
-    return slots * 2 * ts + slots * (h->max_row_deg > 32 ? 16 : 8);
+    (void)prec;
+    return (size_t)h->qc.mb * h->qc.Zp * 32;   // covers the state layout of either QC kernel
 }
 
 static int launch_decode(ldpc_handle *h, int algo, int prec, const DecodeArgs &args)
@@ -946,7 +1043,12 @@ static int launch_decode(ldpc_handle *h, int algo, int prec, const DecodeArgs &a
     Launch L;
     int rc = select_launch(h, algo, prec, args.n_frames, args.chain != nullptr, &L);
     if (rc) return rc;
-    if (h->is_qc) {
+    if (h->is_qc && h->is_regular) {
+        RegTables tb = h->reg;
+        DecodeArgs a = args;
+        void *kargs[] = {&tb, &a};
+        HIP_TRY(hipLaunchKernel(L.fn, dim3(L.grid), dim3(L.block), kargs, L.lds, h->stream));
+    } else if (h->is_qc) {
         QcTables tb = h->qc;
         DecodeArgs a = args;
         void *kargs[] = {&tb, &a};

@@ -1,0 +1,307 @@
+// Throughput kernel for float32 min-sum on regular quasi-cyclic codes with two
+// block-rows of weight-2 circulants (NearEarth (8176,7154) and its variants with
+// zeroed circulants).  Included by ldpc_hip.hip.
+//
+// Measured on MI355X the decode is bound by vector-instruction issue (one
+// wave64 instruction per 4 clocks per SIMD), with the LDS pipe about one third
+// busy, so this kernel trades VALU work for LDS traffic: check-to-variable
+// messages are stored EXPLICITLY in LDS, one record of five dwords per variable
+// node
+//     { posterior, msg(block-row 0, shift 0), msg(0, 1), msg(1, 0), msg(1, 1) }
+// (stride 5 dwords: consecutive columns fall into distinct banks).  The whole
+// frame state is 8176 * 20 B = 163,520 B of the CU's 160 KiB.
+//   check pass, per edge:  2 LDS reads (posterior, previous message) and
+//       7 vector instructions (hard decision, subtract, sign bit, two-minimum
+//       update, argmin), then 1 LDS write and 2 instructions to send
+//       "min1 with sign"; the single edge that must carry min2 instead is
+//       patched per row afterwards;
+//   variable pass, per column: 4 LDS reads, 5 additions, 1 LDS write.
+// Same arithmetic in the same order as the other kernels (ldpc.py:150-163,
+// 174-202, 295-324): results are bit-identical.
+#pragma once
+
+__device__ __forceinline__ float lds_f32(const unsigned char *smem, uint32_t addr)
+{
+    return *reinterpret_cast<const float *>(smem + addr);
+}
+__device__ __forceinline__ void lds_put_f32(unsigned char *smem, uint32_t addr, float v)
+{
+    *reinterpret_cast<float *>(smem + addr) = v;
+}
+__device__ __forceinline__ void lds_put_u32(unsigned char *smem, uint32_t addr, uint32_t v)
+{
+    *reinterpret_cast<uint32_t *>(smem + addr) = v;
+}
+
+template <int Z, int CPT>
+struct PlanesGeom {
+    enum { MB = 2, W = 2, NB = CPT * MB, NS = NB * W, N = NB * Z, ZP = (Z + 63) / 64 * 64,
+           CB = 20,                                  // bytes per column record
+           REC_BYTES = N * CB, SHTAB_OFF = REC_BYTES, SHTAB_BYTES = MB * NB * W * 4,
+           FLAG_OFF = SHTAB_OFF + SHTAB_BYTES, LDS_BYTES = FLAG_OFF + 16 };
+};
+
+// Check pass of one row of block-row B.  FIRST: the row's previous messages are all +0
+// (fresh decoder, checkNode.__init__ ldpc.py:121) and are not read.  Returns the lanes
+// whose parity check on the current hard decisions fails.
+template <int Z, int CPT, bool HOLES, int B, bool FIRST>
+__device__ __forceinline__ unsigned long long
+planes_check_pass(unsigned char *smem, const uint32_t (&radr)[CPT * 4], uint32_t rmask, int D, int sign_mode, int ic)
+{
+    typedef PlanesGeom<Z, CPT> G;
+    enum { NS = G::NS, CH = 8 };
+    const float INF = __uint_as_float(0x7f800000u);
+    float min1 = INF, min2 = INF;
+    uint32_t idx = 0, R = 0;
+    unsigned long long synd = 0;
+#pragma unroll
+    for (int c0 = 0; c0 < NS; c0 += CH) {
+        float p[CH], c[CH];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            const int s = c0 + u;
+            c[u] = 0.0f;
+            if (!HOLES || ((rmask >> (s >> 1)) & 1u)) {
+                p[u] = lds_f32(smem, radr[s]);
+                if (!FIRST) c[u] = lds_f32(smem, radr[s] + 4u * (1 + 2 * B + (s & 1)));
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);   // keep the next chunk's loads from being hoisted up here
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            const int s = c0 + u;
+            if (!HOLES || ((rmask >> (s >> 1)) & 1u)) {
+                synd ^= __ballot(p[u] > 0.0f);                              // slicer, ldpc.py:47
+                const float v = FIRST ? p[u] : p[u] - c[u];                 // receive, ldpc.py:161 (x - 0 == x)
+                R = __builtin_amdgcn_alignbit(R, __float_as_uint(v), 31);   // (R << 1) | sign(v), ldpc.py:139
+                const float av = fabsf(v);                                  // ldpc.py:178
+                const bool lt = av < min1;
+                min2 = __builtin_amdgcn_fmed3f(min1, min2, av);
+                idx = lt ? (uint32_t)s : idx;
+                min1 = fminf(min1, av);
+            }
+            // Pin the running state here.  Otherwise instruction selection defers the whole
+            // second-minimum / argmin / syndrome chains to the end of the pass and keeps every
+            // |v|, every intermediate minimum and every compare mask alive until then
+            // (60+ vector and 60+ scalar registers, spills).
+            if ((u & 3) == 3) {
+                asm volatile("" : "+v"(min1), "+v"(min2), "+v"(idx), "+v"(R), "+s"(synd));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    // R: D sign bits, first edge highest.  Left-align and fold in the product of all signs:
+    // a bit of T is then the sign of the outgoing message itself (ldpc.py:190)
+    if (D < 32) R = D > 0 ? (R << (32 - D)) : 0u;
+    uint32_t S = __popc(R) & 1u;
+    if (sign_mode == LDPC_SIGN_CORRECTED) S ^= (uint32_t)D & 1u;
+    const uint32_t full = D > 0 ? (0xffffffffu << (32 - D)) : 0u;
+    const uint32_t T = R ^ (S ? full : 0u);
+    const uint32_t m1 = __float_as_uint(min1), m2 = __float_as_uint(min2);
+    // every edge gets +-min1 ...
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        if (!HOLES || ((rmask >> (s >> 1)) & 1u)) {
+            const uint32_t rank = HOLES ? (uint32_t)(__popc(rmask & ((1u << (s >> 1)) - 1u)) * 2 + (s & 1)) : (uint32_t)s;
+            lds_put_u32(smem, radr[s] + 4u * (1 + 2 * B + (s & 1)), m1 | ((T << rank) & 0x80000000u));
+        }
+        if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+    // ... except the edge of the smallest magnitude, which gets +-min2 (ldpc.py:191).  Its record
+    // address is recomputed from the shift table (idx differs from lane to lane).
+    {
+        const uint32_t j = idx >> 1, k = idx & 1u;
+        const int sh = *reinterpret_cast<const int *>(smem + G::SHTAB_OFF + ((B * G::NB + j) * 2 + k) * 4);
+        int ci = ic + sh;
+        ci = ci >= Z ? ci - Z : ci;
+        const uint32_t adr = (uint32_t)(j * Z + ci) * G::CB + 4u * (1 + 2 * B) + 4u * k;
+        const uint32_t rank = HOLES ? (uint32_t)__popc(rmask & ((1u << j) - 1u)) * 2 + k : idx;
+        if (D > 0) lds_put_u32(smem, adr, m2 | ((T << rank) & 0x80000000u));
+    }
+    return synd;
+}
+
+// The whole decode loop for the threads of block-row / column-group B.  It is instantiated
+// once per B and the kernel branches ONCE (wave-uniformly) into its copy: with one shared
+// loop and a branch per pass the optimiser merges the common tails of the copies and
+// carries every per-edge intermediate across the merge in registers.
+template <int Z, int CPT, bool HOLES, int B>
+__device__ __forceinline__ void
+planes_role(unsigned char *smem, const RegTables &tb, const DecodeArgs &a)
+{
+    typedef PlanesGeom<Z, CPT> G;
+    enum { MB = G::MB, W = G::W, NB = G::NB, NS = G::NS, N = G::N, ZP = G::ZP, CB = G::CB };
+    static_assert(MB * ZP <= 1024 && NS <= 32, "geometry");
+    static_assert(3 * MB * Z * CB + 4 * 4 < 65536, "column record offsets must fit the DS immediate");
+    int *shtab = reinterpret_cast<int *>(smem + G::SHTAB_OFF);
+    int *flags = reinterpret_cast<int *>(smem + G::FLAG_OFF);    // [2] "syndrome non-zero", [2] ones counters
+
+    const int tid = threadIdx.x;
+    const int g = B;                                             // block-row served / first block-column served
+    const int i = tid - g * ZP;
+    const bool live = i < Z;
+    const int ic = live ? i : 0;
+    const int lane = tid & 63;
+    const int nbytes = (N + 7) >> 3;
+
+    // ---- per-launch set-up
+    for (int x = tid; x < MB * NB * W; x += blockDim.x) shtab[x] = tb.shifts[x];
+    uint32_t rmask = g == 0 ? tb.row_mask[0] : tb.row_mask[1];
+    if (!HOLES) rmask = (1u << NB) - 1u;
+    const uint32_t cm0 = HOLES ? tb.row_mask[0] : rmask, cm1 = HOLES ? tb.row_mask[1] : rmask;
+    const int D = __popc(rmask) * W;
+    uint32_t radr[NS];                       // record address of the column each of my row's edges goes to
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int sh = tb.shifts[(g * NB + (s >> 1)) * W + (s & 1)];
+        int c = ic + sh;
+        c = c >= Z ? c - Z : c;
+        radr[s] = (uint32_t)((s >> 1) * Z + c) * CB;
+    }
+    // my columns: block-column g + q*MB, position ic; records q and q+4 share a base register
+    const uint32_t cadr0 = (uint32_t)(g * Z + ic) * CB;
+    const uint32_t cadr1 = cadr0 + 4u * (MB * Z * CB);
+    // bit q: in block (1, j_q) the row of the lower shift has the lower index
+    uint32_t lomask = 0;
+#pragma unroll
+    for (int q = 0; q < CPT; ++q) {
+        const int j = g + q * MB;
+        const int s0 = tb.shifts[(1 * NB + j) * W + 0], s1 = tb.shifts[(1 * NB + j) * W + 1];
+        if (ic >= s0 && ic < s1) lomask |= 1u << q;
+    }
+
+    // variable pass (ldpc.py:295-311, 321-323): columns (g + q*MB, ic)
+    auto variable_pass = [&](const float (&y)[CPT]) {
+#pragma unroll
+        for (int q = 0; q < CPT; ++q) {
+            const int j = g + q * MB;
+            const uint32_t adr = (q < 4 ? cadr0 : cadr1) + (uint32_t)(q & 3) * (MB * Z * CB);
+            const bool p0 = !HOLES || ((cm0 >> j) & 1u), p1 = !HOLES || ((cm1 >> j) & 1u);
+            float acc = 0.0f;
+            if (p0) {
+                // first two terms of the column sum: 0 + x + y == x + y == y + x
+                acc = lds_f32(smem, adr + 4) + lds_f32(smem, adr + 8);
+            }
+            if (p1) {
+                const float m10 = lds_f32(smem, adr + 12), m11 = lds_f32(smem, adr + 16);
+                if (p0) {
+                    const bool lo = (lomask >> q) & 1u;
+                    acc = acc + (lo ? m10 : m11);             // lower check index first
+                    acc = acc + (lo ? m11 : m10);
+                } else {
+                    acc = m10 + m11;
+                }
+            }
+            lds_put_f32(smem, adr, acc + y[q]);               // channel last, ldpc.py:322
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    const int64_t n_frames = a.n_frames;
+    // Channel values: y of the frame being decoded, ynext of the frame after it (requested when
+    // this frame's decode starts, so HBM latency hides behind the whole decode).
+    float y[CPT], ynext[CPT];
+#pragma unroll
+    for (int q = 0; q < CPT; ++q) ynext[q] = 0.0f;
+    if (live && (int64_t)blockIdx.x < n_frames)
+        load_llr_strided<float, CPT>(a.llr, a.llr_f64, (int64_t)blockIdx.x * N + g * Z + i, MB * Z, ynext);
+#pragma unroll
+    for (int q = 0; q < CPT; ++q) {
+        // "+ 0": -0.0 becomes +0.0 (invisible to every comparison and sum below; keeps
+        // "sign bit set" equivalent to "< 0" for every message)
+        y[q] = ynext[q] * a.llr_scale + 0.0f;
+    }
+    int fpar = 0;
+    if (tid < 4) flags[tid] = 0;
+    for (int64_t frame = blockIdx.x; frame < n_frames; frame += gridDim.x, fpar ^= 1) {
+#pragma unroll
+        for (int q = 0; q < CPT; ++q)
+            if (live) lds_put_f32(smem, (q < 4 ? cadr0 : cadr1) + (uint32_t)(q & 3) * (MB * Z * CB), y[q]);
+        if (live && frame + gridDim.x < n_frames)
+            load_llr_strided<float, CPT>(a.llr, a.llr_f64, (frame + gridDim.x) * N + g * Z + i, MB * Z, ynext);
+        if (tid < 2) flags[tid] = 0;
+        if (tid == 2) flags[2 + fpar] = 0;                // this frame's ones counter (last read two frames ago)
+        int my_iters = 0, my_conv = 0;
+        lds_barrier();
+
+        // ---- iteration 0 is peeled: its check pass has no previous messages to read
+        {
+            if (live) {
+                const unsigned long long synd =
+                    planes_check_pass<Z, CPT, HOLES, B, true>(smem, radr, rmask, D, a.sign_mode, ic);
+                if (synd != 0ull) flags[0] = 1;
+            }
+            lds_barrier();
+            const int bad = flags[0];
+            if (bad == 0 || a.max_iters <= 0) {
+                my_conv = (bad == 0);
+            } else {
+                if (tid == 0) flags[1] = 0;
+                if (live) variable_pass(y);
+                lds_barrier();
+                for (int it = 1;; ++it) {
+                    const int par = it & 1;
+                    if (live) {
+                        const unsigned long long synd =
+                            planes_check_pass<Z, CPT, HOLES, B, false>(smem, radr, rmask, D, a.sign_mode, ic);
+                        if (synd != 0ull) flags[par] = 1;
+                    }
+                    lds_barrier();
+                    const int bad2 = flags[par];                 // stop test, ldpc.py:332-335
+                    if (bad2 == 0 || it >= a.max_iters) {
+                        my_iters = it;
+                        my_conv = (bad2 == 0);
+                        break;
+                    }
+                    if (tid == 0) flags[par ^ 1] = 0;
+                    if (live) variable_pass(y);
+                    lds_barrier();
+                }
+            }
+        }
+
+        // ================= outputs.  Hard decisions: 64 consecutive columns per wave and step,
+        // lane k (k < 8) collects byte k of each step.  The global stores are issued only AFTER
+        // the prefetched channel values have been consumed: vector-memory operations retire in
+        // order, so a wait for those loads placed after the stores would also wait for every
+        // store acknowledgement (measured: 6 us per frame).
+        unsigned long long mybytes = 0;
+        {
+            int wave_ones = 0, t = 0;
+            for (int c0 = (tid & ~63); c0 < N; c0 += blockDim.x, ++t) {
+                const int c = c0 + lane;
+                const float pv = c < N ? lds_f32(smem, (uint32_t)c * CB) : 0.0f;
+                const unsigned long long bits = __ballot(pv > 0.0f);
+                wave_ones += __popcll(bits);
+                mybytes |= ((bits >> (8 * (lane & 7))) & 0xffull) << (8 * t);
+                if (a.soft && c < N) reinterpret_cast<float *>(a.soft)[frame * N + c] = pv;
+            }
+            if (wave_ones && lane == 0) atomicAdd(&flags[2 + fpar], wave_ones);
+        }
+#pragma unroll
+        for (int q = 0; q < CPT; ++q) y[q] = ynext[q] * a.llr_scale + 0.0f;   // waits for the prefetch only
+        lds_barrier();
+        if (a.hard && lane < 8) {
+            int t = 0;
+            for (int c0 = (tid & ~63); c0 < N; c0 += blockDim.x, ++t)
+                if ((c0 >> 3) + lane < nbytes)
+                    a.hard[frame * nbytes + (c0 >> 3) + lane] = (uint8_t)(mybytes >> (8 * t));
+        }
+        if (tid == 0) {
+            if (a.iters) a.iters[frame] = my_iters;
+            if (a.conv) a.conv[frame] = (uint8_t)my_conv;
+            if (a.ones) a.ones[frame] = flags[2 + fpar];
+        }
+    }
+}
+
+template <int Z, int CPT, bool HOLES>
+__global__ void __launch_bounds__(1024)
+qc_planes_kernel(const RegTables tb, const DecodeArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x / PlanesGeom<Z, CPT>::ZP) == 0)
+        planes_role<Z, CPT, HOLES, 0>(smem, tb, a);
+    else
+        planes_role<Z, CPT, HOLES, 1>(smem, tb, a);
+}

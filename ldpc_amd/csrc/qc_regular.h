@@ -1,0 +1,389 @@
+// Fast min-sum kernel for REGULAR quasi-cyclic codes: MB x NB circulant blocks
+// in which every non-empty block is a sum of exactly W cyclic shifts
+// (NearEarth: MB=2, NB=16, W=2; its circulant-zeroed variants: the same with
+// holes; 802.11n: W=1 with holes).  Included by ldpc_hip.hip.
+//
+// What makes it fast compared with the table-driven kernel:
+//   * every LDS address a thread needs -- the NB*W posteriors of its check row
+//     and the MB*W row states of each of its CPT columns -- is computed ONCE per
+//     launch and kept in registers, so an iteration issues no address
+//     arithmetic, no scalar table loads and no divisions;
+//   * the loops over a row's edges and a column's checks are fully unrolled
+//     straight-line code, so the LDS reads of a pass are issued back to back;
+//   * a row's sign bits live in one register that is rotated by one bit per
+//     edge: the bit shifted out at the top is the edge's previous sign, the bit
+//     shifted in at the bottom its new one.
+// Arithmetic and its order are those of the table-driven kernel (ldpc.py:150-163,
+// 174-202, 295-324); results are bit-identical.
+#pragma once
+
+struct RegTables {
+    int Z, Zp, nb, n;
+    uint32_t row_mask[8];    // [MB] bit j set: block (b, j) is present
+    const int32_t *shifts;   // [MB][NB][W] shifts of block (b, j), ascending; unused if absent
+};
+
+template <typename T> struct RegState;
+// float: {min1, min2, sign bits (left aligned, pre-multiplied by the row's sign product), argmin slot}
+template <> struct RegState<float> { enum { BYTES = 16 }; };
+// double: {min1, min2} {sign bits, argmin slot, pad, pad}
+template <> struct RegState<double> { enum { BYTES = 32 }; };
+
+__device__ __forceinline__ uint32_t hi_bits(float v) { return __float_as_uint(v); }
+__device__ __forceinline__ uint32_t hi_bits(double v) { return (uint32_t)__double2hiint(v); }
+
+template <typename T> struct RowStateRegs { T min1, min2; uint32_t signs, idx; };
+
+// LDS image of a row state as it is read by the variable pass
+template <typename T> struct StateRaw;
+template <> struct StateRaw<float> { uint4 v; };
+template <> struct StateRaw<double> { double2 mm; uint2 mt; };
+
+__device__ __forceinline__ void lds_store_state(unsigned char *smem, uint32_t addr, const RowStateRegs<float> &s)
+{
+    *reinterpret_cast<uint4 *>(smem + addr) =
+        make_uint4(__float_as_uint(s.min1), __float_as_uint(s.min2), s.signs, s.idx);
+}
+__device__ __forceinline__ void lds_store_state(unsigned char *smem, uint32_t addr, const RowStateRegs<double> &s)
+{
+    *reinterpret_cast<double2 *>(smem + addr) = make_double2(s.min1, s.min2);
+    *reinterpret_cast<uint2 *>(smem + addr + 16) = make_uint2(s.signs, s.idx);
+}
+__device__ __forceinline__ void lds_load_state(const unsigned char *smem, uint32_t addr, StateRaw<float> &r)
+{
+    r.v = *reinterpret_cast<const uint4 *>(smem + addr);
+}
+__device__ __forceinline__ void lds_load_state(const unsigned char *smem, uint32_t addr, StateRaw<double> &r)
+{
+    r.mm = *reinterpret_cast<const double2 *>(smem + addr);
+    r.mt = *reinterpret_cast<const uint2 *>(smem + addr + 16);
+}
+// message of a row along the edge with slot number `slot` whose sign sits `rank` bits below the top.
+// Magnitudes are never negative, so OR-ing the sign bit in is the multiplication by +-1.
+__device__ __forceinline__ float rebuild_msg(const StateRaw<float> &r, uint32_t slot, uint32_t rank)
+{
+    const uint32_t mag = (r.v.w == slot) ? r.v.y : r.v.x;
+    return __uint_as_float(mag | ((r.v.z << rank) & 0x80000000u));
+}
+__device__ __forceinline__ double rebuild_msg(const StateRaw<double> &r, uint32_t slot, uint32_t rank)
+{
+    const double mag = (r.mt.y == slot) ? r.mm.y : r.mm.x;
+    return __hiloint2double(__double2hiint(mag) | (int)((r.mt.x << rank) & 0x80000000u), __double2loint(mag));
+}
+// previous message of my own row: non-negative magnitude, sign = bit 31 of signword
+__device__ __forceinline__ float with_top_sign(float mag, uint32_t signword)
+{
+    return __uint_as_float(__float_as_uint(mag) | (signword & 0x80000000u));
+}
+__device__ __forceinline__ double with_top_sign(double mag, uint32_t signword)
+{
+    return __hiloint2double(__double2hiint(mag) | (int)(signword & 0x80000000u), __double2loint(mag));
+}
+
+// Identity the optimiser cannot see through: keeps the unpacking of a packed address pair
+// next to its use instead of being hoisted out of the iteration loop into 2x the registers.
+__device__ __forceinline__ uint32_t opaque(uint32_t x)
+{
+    asm volatile("" : "+v"(x));
+    return x;
+}
+
+// LDS-only barrier: waits for this wave's LDS traffic, not for global loads in flight
+// (the next frame's channel values are prefetched across the whole decode of the current one).
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// Thread layout as in the table-driven kernel: t = ((f*MB + g)*Zp + i).
+// LDS: row states | posteriors | flags.  Addresses are kept two to a register (16 bits
+// each); float uses absolute byte addresses, double keeps posterior addresses relative to
+// the start of the posterior region (the two regions together exceed 64 KB).
+template <typename T, int MB, int W, int CPT, int FPW, bool HOLES>
+__global__ void __launch_bounds__(1024)
+qc_regular_kernel(const RegTables tb, const DecodeArgs a)
+{
+    enum { NB = CPT * MB, NS = NB * W, SB = RegState<T>::BYTES, NC = CPT * MB * W, CH = 16 };
+    static_assert(NS <= 32, "sign bits of a row must fit one register");
+    static_assert(NS % 2 == 0 && NC % 2 == 0, "addresses are packed in pairs");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int Z = tb.Z, Zp = tb.Zp, n = tb.n;
+    const int slots = FPW * MB * Zp;
+    const uint32_t state_off = 0;
+    const uint32_t post_off = (uint32_t)slots * SB;
+    const uint32_t flag_off = post_off + (uint32_t)((((size_t)FPW * n * sizeof(T)) + 15) & ~(size_t)15);
+    const uint32_t post_rel = sizeof(T) == 8 ? post_off : 0u;   // added when a packed posterior address is used
+    int *flags = reinterpret_cast<int *>(smem + flag_off);   // [2][FPW] "syndrome non-zero"
+    int *ones_cnt = flags + 2 * FPW;                          // [FPW]
+
+    const int tid = threadIdx.x;
+    const int grp = __builtin_amdgcn_readfirstlane(tid / Zp);
+    const int f = grp / MB;
+    const int g = grp - f * MB;
+    const int i = tid - grp * Zp;
+    const bool live = i < Z;
+    const int ic = live ? i : 0;     // idle lanes compute harmless in-range addresses
+    const int fbase = f * n;
+    const int nbytes = (n + 7) >> 3;
+    const T INF = t_inf(T(0));
+    const uint32_t my_state = state_off + (uint32_t)(grp * Zp + ic) * SB;
+
+    // ---- per-launch set-up: every LDS address this thread will ever use
+    uint32_t rmask = 0;                 // present blocks of my block-row
+#pragma unroll
+    for (int b = 0; b < MB; ++b) rmask = (b == g) ? tb.row_mask[b] : rmask;
+    if (!HOLES) rmask = (NB >= 32) ? 0xffffffffu : ((1u << NB) - 1u);
+    const int D = __popc(rmask) * W;    // check degree of my row
+    uint32_t rpk[NS / 2];               // posterior addresses of my row's edges
+#pragma unroll
+    for (int t = 0; t < NS / 2; ++t) {
+        uint32_t two[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int sl = 2 * t + h, j = sl / W, k = sl % W;
+            const int s = tb.shifts[(g * NB + j) * W + k];
+            int c = ic + s;
+            c = c >= Z ? c - Z : c;
+            two[h] = post_off - post_rel + (uint32_t)(fbase + j * Z + c) * (uint32_t)sizeof(T);
+        }
+        rpk[t] = two[0] | (two[1] << 16);
+    }
+    uint32_t cpk[NC / 2];               // row-state addresses of my columns' checks, flat ((q*MB + b)*W + k)
+    uint32_t lo_first = 0;              // bit q*MB+b: the row of block (b, j_q)'s lower shift has the lower index
+    uint32_t cmask[MB];                 // present blocks of every block-row (uniform)
+#pragma unroll
+    for (int b = 0; b < MB; ++b) cmask[b] = HOLES ? tb.row_mask[b] : rmask;
+#pragma unroll
+    for (int t = 0; t < NC / 2; ++t) {
+        uint32_t two[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int fl = 2 * t + h, q = fl / (MB * W), b = (fl / W) % MB, k = fl % W;
+            const int j = g + q * MB;
+            const int s = tb.shifts[(b * NB + j) * W + k];
+            int r = ic - s;
+            r = r < 0 ? r + Z : r;
+            two[h] = state_off + (uint32_t)((f * MB + b) * Zp + r) * SB;
+            if (W == 2 && k == 0) {
+                const int s1 = tb.shifts[(b * NB + j) * W + (W - 1)];
+                if (ic >= s && ic < s1) lo_first |= 1u << (q * MB + b);
+            }
+        }
+        cpk[t] = two[0] | (two[1] << 16);
+    }
+    uint32_t ypost[1];                  // byte address of my first column's posterior; the others follow at MB*Z elements
+    ypost[0] = post_off + (uint32_t)(fbase + g * Z + ic) * (uint32_t)sizeof(T);
+    const uint32_t col_stride = (uint32_t)(MB * Z) * (uint32_t)sizeof(T);
+
+    RowStateRegs<T> o;                  // messages my row sent last (compressed)
+    o.min1 = T(0); o.min2 = T(0); o.signs = 0; o.idx = 0;
+    unsigned char *chain = a.chain;
+    if (chain && live) {
+        const unsigned char *src = chain + (size_t)(grp * Zp + i) * 32;
+        o.min1 = *reinterpret_cast<const T *>(src);
+        o.min2 = *reinterpret_cast<const T *>(src + 8);
+        o.signs = *reinterpret_cast<const uint32_t *>(src + 16);
+        o.idx = *reinterpret_cast<const uint32_t *>(src + 20);
+    }
+
+    const int64_t n_fblocks = (a.n_frames + FPW - 1) / FPW;
+    // channel values of the first frame; later frames are prefetched during the decode before
+    T ynext[CPT];
+    {
+        const int64_t frame0 = (int64_t)blockIdx.x * FPW + f;
+#pragma unroll
+        for (int q = 0; q < CPT; ++q) ynext[q] = T(0);
+        if (live && blockIdx.x < n_fblocks && frame0 < a.n_frames)
+            load_llr_strided<T, CPT>(a.llr, a.llr_f64, frame0 * n + g * Z + i, MB * Z, ynext);
+    }
+    for (int64_t fb = blockIdx.x; fb < n_fblocks; fb += gridDim.x) {
+        const int64_t frame = fb * FPW + f;
+        const bool valid = frame < a.n_frames;
+        T y[CPT];
+#pragma unroll
+        for (int q = 0; q < CPT; ++q) {
+            // "+ 0": a -0.0 input becomes +0.0, which no comparison or sum below can tell
+            // apart, and which keeps "sign bit set" equivalent to "< 0" for every message
+            y[q] = ynext[q] * T(a.llr_scale) + T(0);
+            if (live && valid)
+                *reinterpret_cast<T *>(smem + ypost[0] + (uint32_t)q * col_stride) = y[q];
+        }
+        {
+            const int64_t fbn = fb + gridDim.x;
+            const int64_t framen = fbn * FPW + f;
+            if (live && fbn < n_fblocks && framen < a.n_frames)
+                load_llr_strided<T, CPT>(a.llr, a.llr_f64, framen * n + g * Z + i, MB * Z, ynext);
+        }
+        if (tid < 3 * FPW) flags[tid] = 0;
+        if (!chain) { o.min1 = T(0); o.min2 = T(0); o.signs = 0; o.idx = 0; }
+        uint32_t act_mask = 0;
+#pragma unroll
+        for (int ff = 0; ff < FPW; ++ff)
+            if (fb * FPW + ff < a.n_frames) act_mask |= 1u << ff;
+        int my_iters = 0, my_conv = 0;
+        lds_barrier();
+
+        for (int it = 0;; ++it) {
+            const bool active = (act_mask >> f) & 1u;
+            const int par = it & 1;
+            // ================= check pass (+ syndrome of the current posterior)
+            RowStateRegs<T> nw;
+            nw.min1 = INF; nw.min2 = INF; nw.idx = 0; nw.signs = 0;
+            if (active && live) {
+                unsigned long long synd = 0;
+                uint32_t R = o.signs;                     // top bit = previous sign of the next edge
+#pragma unroll
+                for (int c0 = 0; c0 < NS; c0 += CH) {
+                    T p[CH];
+#pragma unroll
+                    for (int u = 0; u < CH; ++u) {
+                        const int s = c0 + u;
+                        if (s < NS && (!HOLES || ((rmask >> (s / W)) & 1u))) {
+                            const uint32_t ad = ((s & 1) ? (opaque(rpk[s / 2]) >> 16) : (opaque(rpk[s / 2]) & 0xffffu)) + post_rel;
+                            p[u] = *reinterpret_cast<const T *>(smem + ad);
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < CH; ++u) {
+                        const int s = c0 + u;
+                        if (s < NS && (!HOLES || ((rmask >> (s / W)) & 1u))) {
+                            synd ^= __ballot(p[u] > T(0));                       // slicer, ldpc.py:47
+                            const T mag_old = (o.idx == (uint32_t)s) ? o.min2 : o.min1;
+                            const T v = p[u] - with_top_sign(mag_old, R);        // receive, ldpc.py:161
+                            R = __builtin_amdgcn_alignbit(R, hi_bits(v), 31);    // (R << 1) | sign(v), ldpc.py:139
+                            const T av = t_abs(v);                               // ldpc.py:178
+                            const bool lt = av < nw.min1;
+                            nw.min2 = t_mid(nw.min1, nw.min2, av);
+                            nw.idx = lt ? (uint32_t)s : nw.idx;
+                            nw.min1 = t_min(nw.min1, av);
+                        }
+                    }
+                }
+                // R: D new sign bits, first edge highest.  Left-align; fold in the product of all
+                // signs so that a bit is directly the sign of the outgoing message (ldpc.py:190)
+                if (D < 32) R = D > 0 ? (R << (32 - D)) : 0u;
+                uint32_t S = __popc(R) & 1u;
+                if (a.sign_mode == LDPC_SIGN_CORRECTED) S ^= (uint32_t)D & 1u;
+                const uint32_t full = D > 0 ? (0xffffffffu << (32 - D)) : 0u;
+                nw.signs = R ^ (S ? full : 0u);
+                lds_store_state(smem, my_state, nw);
+                if (synd != 0ull) flags[par * FPW + f] = 1;
+            }
+            lds_barrier();
+            // ================= stop test (ldpc.py:332-335), same outcome in every thread
+            uint32_t next_mask = 0;
+#pragma unroll
+            for (int ff = 0; ff < FPW; ++ff) {
+                if ((act_mask >> ff) & 1u) {
+                    const int bad = flags[par * FPW + ff];
+                    if (bad != 0 && it < a.max_iters) {
+                        next_mask |= 1u << ff;
+                    } else if (ff == f) {
+                        my_iters = it;
+                        my_conv = (bad == 0);
+                    }
+                }
+            }
+            act_mask = next_mask;
+            if (act_mask == 0) break;
+            // a row's new messages replace its previous ones only if its frame goes on
+            if (((act_mask >> f) & 1u) && live) o = nw;
+            if (tid < FPW) flags[(par ^ 1) * FPW + tid] = 0;
+            // ================= variable pass (ldpc.py:295-311, 321-323)
+            if (((act_mask >> f) & 1u) && live) {
+#pragma unroll
+                for (int q0 = 0; q0 < CPT; q0 += 2) {
+                    StateRaw<T> st[2][MB][W];
+#pragma unroll
+                    for (int dq = 0; dq < 2; ++dq)
+#pragma unroll
+                        for (int b = 0; b < MB; ++b)
+#pragma unroll
+                            for (int k = 0; k < W; ++k) {
+                                const int q = q0 + dq, fl = (q * MB + b) * W + k;
+                                const int j = g + q * MB;
+                                if (q < CPT && (!HOLES || ((cmask[b] >> j) & 1u))) {
+                                    const uint32_t ad = (fl & 1) ? (opaque(cpk[fl / 2]) >> 16) : (opaque(cpk[fl / 2]) & 0xffffu);
+                                    lds_load_state(smem, ad, st[dq][b][k]);
+                                }
+                            }
+#pragma unroll
+                    for (int dq = 0; dq < 2; ++dq) {
+                        const int q = q0 + dq;
+                        if (q < CPT) {
+                            const int j = g + q * MB;
+                            T acc = T(0);
+                            bool first_group = true;
+#pragma unroll
+                            for (int b = 0; b < MB; ++b) {
+                                if (!HOLES || ((cmask[b] >> j) & 1u)) {
+                                    // rank of the block's first edge among the present edges of block-row b
+                                    const uint32_t rank = HOLES ? (uint32_t)(__popc(cmask[b] & ((1u << j) - 1u)) * W)
+                                                                : (uint32_t)(j * W);
+                                    if (W == 1) {
+                                        acc = acc + rebuild_msg(st[dq][b][0], (uint32_t)(j * W), rank);
+                                    } else {
+                                        const T v0 = rebuild_msg(st[dq][b][0], (uint32_t)(j * W), rank);
+                                        const T v1 = rebuild_msg(st[dq][b][W - 1], (uint32_t)(j * W + 1), rank + 1);
+                                        if (first_group && !HOLES) {
+                                            // first two terms of the column sum: 0 + x + y == x + y == y + x
+                                            acc = v0 + v1;
+                                        } else {
+                                            const bool lf = (lo_first >> (q * MB + b)) & 1u;
+                                            acc = acc + (lf ? v0 : v1);     // lower check index first
+                                            acc = acc + (lf ? v1 : v0);
+                                        }
+                                    }
+                                    first_group = false;
+                                }
+                            }
+                            *reinterpret_cast<T *>(smem + ypost[0] + (uint32_t)q * col_stride) = acc + y[q];   // channel last, ldpc.py:322
+                        }
+                    }
+                }
+            }
+            lds_barrier();
+        }
+
+        // ================= outputs
+        const T *post = reinterpret_cast<const T *>(smem + post_off);
+        for (int x = tid; x < FPW * nbytes; x += blockDim.x) {
+            const int ff = x / nbytes;
+            const int qb = x - ff * nbytes;
+            const int64_t fr = fb * FPW + ff;
+            if (fr < a.n_frames) {
+                uint32_t byte = 0;
+                const int c0 = qb * 8;
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (c0 + k < n) byte |= (uint32_t)(post[ff * n + c0 + k] > T(0)) << k;
+                if (a.hard) a.hard[fr * nbytes + qb] = (uint8_t)byte;
+                if (byte) atomicAdd(&ones_cnt[ff], (int)__popc(byte));
+            }
+        }
+        if (a.soft && valid && live) {
+            T *so = reinterpret_cast<T *>(a.soft) + frame * n;
+#pragma unroll
+            for (int q = 0; q < CPT; ++q) {
+                const int j = g + q * MB;
+                so[j * Z + i] = post[fbase + j * Z + i];
+            }
+        }
+        lds_barrier();
+        if (valid && g == 0 && i == 0) {
+            if (a.iters) a.iters[frame] = my_iters;
+            if (a.conv) a.conv[frame] = (uint8_t)my_conv;
+            if (a.ones) a.ones[frame] = ones_cnt[f];
+        }
+        lds_barrier();
+    }
+    if (chain && live) {
+        unsigned char *dst = chain + (size_t)(grp * Zp + i) * 32;
+        *reinterpret_cast<T *>(dst) = o.min1;
+        *reinterpret_cast<T *>(dst + 8) = o.min2;
+        *reinterpret_cast<uint32_t *>(dst + 16) = o.signs;
+        *reinterpret_cast<uint32_t *>(dst + 20) = o.idx;
+    }
+}

@@ -21,6 +21,7 @@ the reference builds its own, ldpc.py:397) instead of a 2-process pool
 import copy
 import hashlib
 import os
+import threading
 import time
 
 import numpy as np
@@ -64,25 +65,31 @@ def modulate(vector, length):
 
 # ------------------------------------------------------------------ decoder cache
 _DECODERS = {}
-_DECODERS_MAX = 8
+_DECODERS_MAX = 16
+_DECODERS_LOCK = threading.Lock()
 
 
-def _engine_for(H, device=None):
+def _engine_for(H, device=None, physical_device=None):
     """HIP decoder for H (dense array or codes.QCCode).  The gym hands over a new
     dense matrix at every step (ldpc_env.py:313, 370), so engines are cached by
-    content and the least recently used one is dropped."""
+    content and the least recently used one is dropped.  `device` is the caller's
+    (logical) device number and part of the cache key -- a handle serves one host
+    thread at a time, so two logical devices never share one even when they map
+    to the same physical device (`physical_device`, default = `device`)."""
     device = LDPC_HIP_DEVICE if device is None else device
+    physical_device = device if physical_device is None else physical_device
     if isinstance(H, codes.QCCode):
         key = (device,) + H.key()
     else:
         Ha = np.ascontiguousarray(np.asarray(H) != 0)
         key = (device, Ha.shape, hashlib.sha1(np.packbits(Ha).tobytes()).hexdigest())
-    eng = _DECODERS.pop(key, None)
-    if eng is None:
-        eng = Decoder(H, device=device)
-        while len(_DECODERS) >= _DECODERS_MAX:
-            _DECODERS.pop(next(iter(_DECODERS))).close()
-    _DECODERS[key] = eng
+    with _DECODERS_LOCK:
+        eng = _DECODERS.pop(key, None)
+        if eng is None:
+            eng = Decoder(H, device=physical_device)
+            while len(_DECODERS) >= _DECODERS_MAX:
+                _DECODERS.pop(next(iter(_DECODERS))).close()
+        _DECODERS[key] = eng
     return eng
 
 

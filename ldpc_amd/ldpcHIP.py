@@ -59,7 +59,7 @@ def evaluateCodeCuda(seed, SNRpoints, numberOfIterations, parityMatrix, numOfTra
     assert (seed > 0)
     assert hasattr(SNRpoints, "__len__")
     n_dev = max(device_count(), 1)
-    eng = _ldpc._engine_for(parityMatrix, cudaDeviceNumber % n_dev)
+    eng = _ldpc._engine_for(parityMatrix, cudaDeviceNumber, cudaDeviceNumber % n_dev)
     n = eng.n
     berStats = common.berStatistics()
     if deviceRng:

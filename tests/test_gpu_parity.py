@@ -5,6 +5,7 @@
   * size-independent properties at bench scale.
 """
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -19,11 +20,18 @@ def engines():
     import ldpc_amd
     cache = {}
 
-    def get(name):
-        if name not in cache:
+    def get(name, generic=False):
+        """generic=True: force the table-driven QC kernel even where the unrolled
+        kernel for regular codes applies (the library reads the variable at creation)."""
+        key = (name, generic)
+        if key not in cache:
             qc, H = build_code(name)
-            cache[name] = ldpc_amd.Decoder(qc if qc is not None else H)
-        return cache[name]
+            os.environ['LDPC_HIP_FORCE_GENERIC'] = '1' if generic else '0'
+            try:
+                cache[key] = ldpc_amd.Decoder(qc if qc is not None else H)
+            finally:
+                os.environ.pop('LDPC_HIP_FORCE_GENERIC', None)
+        return cache[key]
     yield get
     for e in cache.values():
         e.close()
@@ -42,6 +50,21 @@ def test_f64_bit_exact_against_reference_golden(engines, name):
             if pt['iters'][k] == 0:
                 continue    # the host mirror returns the input itself for 0 iterations
             assert hashlib.sha256(r['soft'][k].tobytes()).digest() == bytes(pt['sha'][k]), (name, pt['seed'], k)
+
+
+@pytest.mark.parametrize('name', ['nearEarth', 'nearEarth_zero_1_3', 'wifi_5_6'])
+def test_table_driven_kernel_on_regular_codes(engines, oracle_mod, name):
+    """Codes the unrolled kernel takes by default, pushed through the table-driven one."""
+    eng = engines(name, generic=True)
+    _, H = build_code(name)
+    orc = oracle_mod.Oracle(H)
+    for pt in golden_points(name):
+        Y = pt['llr'][:8]
+        r = eng.decode(Y, pt['max_iters'], prec=64, want_soft=True)
+        assert np.array_equal(r['iters'], pt['iters'][:8]) and np.array_equal(r['hard_packed'], pt['hard'][:8])
+        hard, iters, conv, soft = orc.minsum(Y, 50, prec=32, threads=8)
+        r = eng.decode(Y, 50, prec=32, want_soft=True)
+        assert np.array_equal(r['iters'], iters) and np.array_equal(r['soft'], soft)
 
 
 @pytest.mark.parametrize('name', ALL_CODES)
