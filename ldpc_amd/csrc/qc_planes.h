@@ -33,6 +33,25 @@ __device__ __forceinline__ void lds_put_u32(unsigned char *smem, uint32_t addr, 
     *reinterpret_cast<uint32_t *>(smem + addr) = v;
 }
 
+// Channel values of one frame for this thread's CPT columns.  `frame_base` is uniform (scalar
+// registers) and the per-lane part is a 32-bit element offset, laundered so that it is
+// recomputed at each use instead of being kept (as CPT 64-bit addresses) across the decode loop.
+template <int CPT>
+__device__ __forceinline__ void
+planes_load_frame(const void *llr, int is_f64, int64_t frame_base, uint32_t first, uint32_t stride, float (&out)[CPT])
+{
+    first = opaque(first);
+    if (is_f64) {
+        const double *p = reinterpret_cast<const double *>(llr) + frame_base;
+#pragma unroll
+        for (int q = 0; q < CPT; ++q) out[q] = (float)p[first + (uint32_t)q * stride];
+    } else {
+        const float *p = reinterpret_cast<const float *>(llr) + frame_base;
+#pragma unroll
+        for (int q = 0; q < CPT; ++q) out[q] = p[first + (uint32_t)q * stride];
+    }
+}
+
 template <int Z, int CPT>
 struct PlanesGeom {
     enum { MB = 2, W = 2, NB = CPT * MB, NS = NB * W, N = NB * Z, ZP = (Z + 63) / 64 * 64,
@@ -130,7 +149,8 @@ __device__ __forceinline__ void
 planes_role(unsigned char *smem, const RegTables &tb, const DecodeArgs &a)
 {
     typedef PlanesGeom<Z, CPT> G;
-    enum { MB = G::MB, W = G::W, NB = G::NB, NS = G::NS, N = G::N, ZP = G::ZP, CB = G::CB };
+    enum { MB = G::MB, W = G::W, NB = G::NB, NS = G::NS, N = G::N, ZP = G::ZP, CB = G::CB,
+           NT = MB * G::ZP };                    // threads per workgroup
     static_assert(MB * ZP <= 1024 && NS <= 32, "geometry");
     static_assert(3 * MB * Z * CB + 4 * 4 < 65536, "column record offsets must fit the DS immediate");
     int *shtab = reinterpret_cast<int *>(smem + G::SHTAB_OFF);
@@ -145,7 +165,7 @@ planes_role(unsigned char *smem, const RegTables &tb, const DecodeArgs &a)
     const int nbytes = (N + 7) >> 3;
 
     // ---- per-launch set-up
-    for (int x = tid; x < MB * NB * W; x += blockDim.x) shtab[x] = tb.shifts[x];
+    for (int x = tid; x < MB * NB * W; x += NT) shtab[x] = tb.shifts[x];
     uint32_t rmask = g == 0 ? tb.row_mask[0] : tb.row_mask[1];
     if (!HOLES) rmask = (1u << NB) - 1u;
     const uint32_t cm0 = HOLES ? tb.row_mask[0] : rmask, cm1 = HOLES ? tb.row_mask[1] : rmask;
@@ -198,31 +218,64 @@ planes_role(unsigned char *smem, const RegTables &tb, const DecodeArgs &a)
     };
 
     const int64_t n_frames = a.n_frames;
-    // Channel values: y of the frame being decoded, ynext of the frame after it (requested when
-    // this frame's decode starts, so HBM latency hides behind the whole decode).
+    // Channel values: y of the frame being decoded, ynext of the frame after it.
     float y[CPT], ynext[CPT];
 #pragma unroll
     for (int q = 0; q < CPT; ++q) ynext[q] = 0.0f;
     if (live && (int64_t)blockIdx.x < n_frames)
-        load_llr_strided<float, CPT>(a.llr, a.llr_f64, (int64_t)blockIdx.x * N + g * Z + i, MB * Z, ynext);
+        planes_load_frame<CPT>(a.llr, a.llr_f64, (int64_t)blockIdx.x * N, (uint32_t)(g * Z + ic), MB * Z, ynext);
 #pragma unroll
     for (int q = 0; q < CPT; ++q) {
         // "+ 0": -0.0 becomes +0.0 (invisible to every comparison and sum below; keeps
         // "sign bit set" equivalent to "< 0" for every message)
         y[q] = ynext[q] * a.llr_scale + 0.0f;
     }
-    int fpar = 0;
     if (tid < 4) flags[tid] = 0;
-    for (int64_t frame = blockIdx.x; frame < n_frames; frame += gridDim.x, fpar ^= 1) {
+
+    // Results of the previous frame, held in registers until the next frame's first check pass
+    // is under way.  A CU takes thousands of cycles to queue one frame's worth of global
+    // loads and stores (measured: a workgroup that issues them between two barriers idles
+    // for 2-3 us per frame); issued here they queue while the other waves do arithmetic.
+    unsigned long long out_bits = 0;             // lane t < 8: hard decisions of columns 64*wave + NT*t ...
+    int64_t out_frame = -1;
+    int out_iters = 0, out_conv = 0, out_ones = 0;
+    auto flush_outputs = [&]() {
+        if (out_frame < 0) return;
+        if (a.hard && lane < 8) {
+            const int b0 = (int)(opaque((uint32_t)(tid & ~63)) + (uint32_t)lane * NT) >> 3;
+            uint8_t *dst = a.hard + out_frame * nbytes + b0;
+            if (b0 + 8 <= nbytes) {
+                __builtin_memcpy(dst, &out_bits, 8);
+            } else {
+                for (int k = 0; b0 + k < nbytes; ++k) dst[k] = (uint8_t)(out_bits >> (8 * k));
+            }
+        }
+        if (tid == 0) {
+            if (a.iters) a.iters[out_frame] = out_iters;
+            if (a.conv) a.conv[out_frame] = (uint8_t)out_conv;
+            if (a.ones) a.ones[out_frame] = out_ones;
+        }
+    };
+
+    for (int64_t frame = blockIdx.x; frame < n_frames; frame += gridDim.x) {
+#ifdef LDPC_TRACE
+        unsigned long long tr[10];
+#define TRACE(k) tr[k] = clock64()
+#else
+#define TRACE(k)
+#endif
+        TRACE(0);
 #pragma unroll
         for (int q = 0; q < CPT; ++q)
             if (live) lds_put_f32(smem, (q < 4 ? cadr0 : cadr1) + (uint32_t)(q & 3) * (MB * Z * CB), y[q]);
-        if (live && frame + gridDim.x < n_frames)
-            load_llr_strided<float, CPT>(a.llr, a.llr_f64, (frame + gridDim.x) * N + g * Z + i, MB * Z, ynext);
-        if (tid < 2) flags[tid] = 0;
-        if (tid == 2) flags[2 + fpar] = 0;                // this frame's ones counter (last read two frames ago)
+        if (tid < 3) flags[tid] = 0;                      // two stop flags, ones counter
         int my_iters = 0, my_conv = 0;
+        TRACE(1);
         lds_barrier();
+        TRACE(2);
+        if (live && frame + gridDim.x < n_frames)
+            planes_load_frame<CPT>(a.llr, a.llr_f64, (frame + gridDim.x) * N, (uint32_t)(g * Z + ic), MB * Z, ynext);
+        flush_outputs();
 
         // ---- iteration 0 is peeled: its check pass has no previous messages to read
         {
@@ -231,8 +284,10 @@ planes_role(unsigned char *smem, const RegTables &tb, const DecodeArgs &a)
                     planes_check_pass<Z, CPT, HOLES, B, true>(smem, radr, rmask, D, a.sign_mode, ic);
                 if (synd != 0ull) flags[0] = 1;
             }
+            TRACE(3);
             lds_barrier();
-            const int bad = flags[0];
+            TRACE(4);
+            const int bad = __builtin_amdgcn_readfirstlane(flags[0]);
             if (bad == 0 || a.max_iters <= 0) {
                 my_conv = (bad == 0);
             } else {
@@ -247,7 +302,7 @@ planes_role(unsigned char *smem, const RegTables &tb, const DecodeArgs &a)
                         if (synd != 0ull) flags[par] = 1;
                     }
                     lds_barrier();
-                    const int bad2 = flags[par];                 // stop test, ldpc.py:332-335
+                    const int bad2 = __builtin_amdgcn_readfirstlane(flags[par]);   // stop test, ldpc.py:332-335
                     if (bad2 == 0 || it >= a.max_iters) {
                         my_iters = it;
                         my_conv = (bad2 == 0);
@@ -260,39 +315,58 @@ planes_role(unsigned char *smem, const RegTables &tb, const DecodeArgs &a)
             }
         }
 
-        // ================= outputs.  Hard decisions: 64 consecutive columns per wave and step,
-        // lane k (k < 8) collects byte k of each step.  The global stores are issued only AFTER
-        // the prefetched channel values have been consumed: vector-memory operations retire in
-        // order, so a wait for those loads placed after the stores would also wait for every
-        // store acknowledgement (measured: 6 us per frame).
-        unsigned long long mybytes = 0;
+        // ---- hard decisions: 64 consecutive columns per wave and step; lane t keeps step t
+        TRACE(5);
+        unsigned long long mine = 0;
         {
-            int wave_ones = 0, t = 0;
-            for (int c0 = (tid & ~63); c0 < N; c0 += blockDim.x, ++t) {
-                const int c = c0 + lane;
-                const float pv = c < N ? lds_f32(smem, (uint32_t)c * CB) : 0.0f;
-                const unsigned long long bits = __ballot(pv > 0.0f);
-                wave_ones += __popcll(bits);
-                mybytes |= ((bits >> (8 * (lane & 7))) & 0xffull) << (8 * t);
-                if (a.soft && c < N) reinterpret_cast<float *>(a.soft)[frame * N + c] = pv;
-            }
-            if (wave_ones && lane == 0) atomicAdd(&flags[2 + fpar], wave_ones);
-        }
+            enum { STEPS = (N + NT - 1) / NT };
+            float pv[STEPS];
 #pragma unroll
-        for (int q = 0; q < CPT; ++q) y[q] = ynext[q] * a.llr_scale + 0.0f;   // waits for the prefetch only
+            for (int t = 0; t < STEPS; ++t) {
+                const int c = (tid & ~63) + t * NT + lane;
+                pv[t] = c < N ? lds_f32(smem, (uint32_t)c * CB) : 0.0f;
+            }
+            int wave_ones = 0;
+#pragma unroll
+            for (int t = 0; t < STEPS; ++t) {
+                const unsigned long long bits = __ballot(pv[t] > 0.0f);
+                wave_ones += __popcll(bits);
+                mine = lane == t ? bits : mine;
+            }
+            if (wave_ones && lane == 0) atomicAdd(&flags[2], wave_ones);
+#ifndef LDPC_TRACE
+            if (a.soft) {
+                const int w0 = (int)opaque((uint32_t)(tid & ~63));
+#pragma unroll
+                for (int t = 0; t < STEPS; ++t) {
+                    const int c = w0 + t * NT + lane;
+                    if (c < N) reinterpret_cast<float *>(a.soft)[frame * N + c] = pv[t];
+                }
+            }
+#endif
+        }
+        TRACE(6);
+#pragma unroll
+        for (int q = 0; q < CPT; ++q) y[q] = ynext[q] * a.llr_scale + 0.0f;
+#ifdef LDPC_TRACE
+        asm volatile("" : "+v"(y[0]), "+v"(y[7]));
+#endif
+        TRACE(7);
         lds_barrier();
-        if (a.hard && lane < 8) {
-            int t = 0;
-            for (int c0 = (tid & ~63); c0 < N; c0 += blockDim.x, ++t)
-                if ((c0 >> 3) + lane < nbytes)
-                    a.hard[frame * nbytes + (c0 >> 3) + lane] = (uint8_t)(mybytes >> (8 * t));
-        }
-        if (tid == 0) {
-            if (a.iters) a.iters[frame] = my_iters;
-            if (a.conv) a.conv[frame] = (uint8_t)my_conv;
-            if (a.ones) a.ones[frame] = flags[2 + fpar];
-        }
+        TRACE(8);
+        out_bits = mine;
+        out_frame = frame;
+        out_iters = my_iters;
+        out_conv = my_conv;
+        out_ones = __builtin_amdgcn_readfirstlane(flags[2]);
+#ifdef LDPC_TRACE
+        TRACE(9);
+        if (lane == 0 && a.soft)
+            for (int k = 0; k < 10; ++k)
+                reinterpret_cast<unsigned long long *>(a.soft)[(frame * 16 + (tid >> 6)) * 16 + k] = tr[k];
+#endif
     }
+    flush_outputs();
 }
 
 template <int Z, int CPT, bool HOLES>
