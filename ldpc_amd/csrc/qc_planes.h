@@ -52,6 +52,24 @@ planes_load_frame(const void *llr, int is_f64, int64_t frame_base, uint32_t firs
     }
 }
 
+// s_setprio with a value that is constant only after unrolling
+__device__ __forceinline__ void set_wave_prio(int p)
+{
+    switch (p) {
+    case 0: __builtin_amdgcn_s_setprio(0); break;
+    case 1: __builtin_amdgcn_s_setprio(1); break;
+    case 2: __builtin_amdgcn_s_setprio(2); break;
+    default: __builtin_amdgcn_s_setprio(3); break;
+    }
+}
+
+#ifndef PLANES_CH
+#define PLANES_CH 4                 // edges per pipeline stage of the check pass
+#endif
+#ifndef PLANES_VB
+#define PLANES_VB 4                 // columns per batch of the variable pass
+#endif
+
 template <int Z, int CPT>
 struct PlanesGeom {
     enum { MB = 2, W = 2, NB = CPT * MB, NS = NB * W, N = NB * Z, ZP = (Z + 63) / 64 * 64,
@@ -68,36 +86,49 @@ __device__ __forceinline__ unsigned long long
 planes_check_pass(unsigned char *smem, const uint32_t (&radr)[CPT * 4], uint32_t rmask, int D, int sign_mode, int ic)
 {
     typedef PlanesGeom<Z, CPT> G;
-    enum { NS = G::NS, CH = 8 };
+    enum { NS = G::NS, CH = PLANES_CH, NCH = NS / CH };
     const float INF = __uint_as_float(0x7f800000u);
     float min1 = INF, min2 = INF;
     uint32_t idx = 0, R = 0;
     unsigned long long synd = 0;
+    // Software pipeline over chunks of CH edges: the LDS reads of chunk k+1 are in flight
+    // while chunk k is reduced, so a wave's own LDS latency is covered even when its three
+    // SIMD neighbours are waiting too (right after a barrier all of them are).
+    float p[2][CH], c[2][CH];
 #pragma unroll
-    for (int c0 = 0; c0 < NS; c0 += CH) {
-        float p[CH], c[CH];
+    for (int k = -1; k < NCH; ++k) {
+        if (k + 1 < NCH) {
+            const int nb = (k + 1) & 1;
 #pragma unroll
-        for (int u = 0; u < CH; ++u) {
-            const int s = c0 + u;
-            c[u] = 0.0f;
-            if (!HOLES || ((rmask >> (s >> 1)) & 1u)) {
-                p[u] = lds_f32(smem, radr[s]);
-                if (!FIRST) c[u] = lds_f32(smem, radr[s] + 4u * (1 + 2 * B + (s & 1)));
+            for (int u = 0; u < CH; ++u) {
+                const int s = (k + 1) * CH + u;
+                c[nb][u] = 0.0f;
+                if (!HOLES || ((rmask >> (s >> 1)) & 1u)) {
+                    p[nb][u] = lds_f32(smem, radr[s]);
+                    if (!FIRST) c[nb][u] = lds_f32(smem, radr[s] + 4u * (1 + 2 * B + (s & 1)));
+                }
             }
         }
-        __builtin_amdgcn_sched_barrier(0);   // keep the next chunk's loads from being hoisted up here
+        __builtin_amdgcn_sched_barrier(0);
+        if (k < 0) continue;
+        // The issue arbiter favours the oldest wave, which would let each SIMD's four waves
+        // finish the pass one after the other, the last one alone with its LDS latency
+        // exposed.  Dropping priority as the pass advances keeps the waves level
+        // (measured: 11 % off the iteration time; finer steps than one per 8 edges were slower).
+        if (k * CH % 8 == 0) set_wave_prio(3 - (k * CH / 8) * 3 / (NS / 8 - 1));
+        const int cb = k & 1;
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
-            const int s = c0 + u;
+            const int s = k * CH + u;
             if (!HOLES || ((rmask >> (s >> 1)) & 1u)) {
-                synd ^= __ballot(p[u] > 0.0f);                              // slicer, ldpc.py:47
-                const float v = FIRST ? p[u] : p[u] - c[u];                 // receive, ldpc.py:161 (x - 0 == x)
+                synd ^= __ballot(p[cb][u] > 0.0f);                          // slicer, ldpc.py:47
+                const float v = FIRST ? p[cb][u] : p[cb][u] - c[cb][u];     // receive, ldpc.py:161 (x - 0 == x)
                 R = __builtin_amdgcn_alignbit(R, __float_as_uint(v), 31);   // (R << 1) | sign(v), ldpc.py:139
                 const float av = fabsf(v);                                  // ldpc.py:178
                 const bool lt = av < min1;
                 min2 = __builtin_amdgcn_fmed3f(min1, min2, av);
                 idx = lt ? (uint32_t)s : idx;
-                min1 = fminf(min1, av);
+                min1 = __builtin_amdgcn_fmed3f(min1, av, -INF);             // min(min1, av) without a canonicalising extra
             }
             // Pin the running state here.  Otherwise instruction selection defers the whole
             // second-minimum / argmin / syndrome chains to the end of the pass and keeps every
@@ -117,6 +148,9 @@ planes_check_pass(unsigned char *smem, const uint32_t (&radr)[CPT * 4], uint32_t
     const uint32_t full = D > 0 ? (0xffffffffu << (32 - D)) : 0u;
     const uint32_t T = R ^ (S ? full : 0u);
     const uint32_t m1 = __float_as_uint(min1), m2 = __float_as_uint(min2);
+    // shift of the arg-min edge, needed after the loop below (idx differs from lane to lane)
+    const uint32_t ej = idx >> 1, ek = idx & 1u;
+    const int esh = *reinterpret_cast<const int *>(smem + G::SHTAB_OFF + ((B * G::NB + ej) * 2 + ek) * 4);
     // every edge gets +-min1 ...
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
@@ -126,15 +160,12 @@ planes_check_pass(unsigned char *smem, const uint32_t (&radr)[CPT * 4], uint32_t
         }
         if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
-    // ... except the edge of the smallest magnitude, which gets +-min2 (ldpc.py:191).  Its record
-    // address is recomputed from the shift table (idx differs from lane to lane).
+    // ... except the edge of the smallest magnitude, which gets +-min2 (ldpc.py:191)
     {
-        const uint32_t j = idx >> 1, k = idx & 1u;
-        const int sh = *reinterpret_cast<const int *>(smem + G::SHTAB_OFF + ((B * G::NB + j) * 2 + k) * 4);
-        int ci = ic + sh;
+        int ci = ic + esh;
         ci = ci >= Z ? ci - Z : ci;
-        const uint32_t adr = (uint32_t)(j * Z + ci) * G::CB + 4u * (1 + 2 * B) + 4u * k;
-        const uint32_t rank = HOLES ? (uint32_t)__popc(rmask & ((1u << j) - 1u)) * 2 + k : idx;
+        const uint32_t adr = (uint32_t)(ej * Z + ci) * G::CB + 4u * (1 + 2 * B) + 4u * ek;
+        const uint32_t rank = HOLES ? (uint32_t)__popc(rmask & ((1u << ej) - 1u)) * 2 + ek : idx;
         if (D > 0) lds_put_u32(smem, adr, m2 | ((T << rank) & 0x80000000u));
     }
     return synd;
@@ -176,7 +207,8 @@ planes_role(unsigned char *smem, const RegTables &tb, const DecodeArgs &a)
         const int sh = tb.shifts[(g * NB + (s >> 1)) * W + (s & 1)];
         int c = ic + sh;
         c = c >= Z ? c - Z : c;
-        radr[s] = (uint32_t)((s >> 1) * Z + c) * CB;
+        // laundered: otherwise the per-block constant is split off and re-added at every use
+        radr[s] = opaque((uint32_t)((s >> 1) * Z + c) * CB);
     }
     // my columns: block-column g + q*MB, position ic; records q and q+4 share a base register
     const uint32_t cadr0 = (uint32_t)(g * Z + ic) * CB;
@@ -192,27 +224,41 @@ planes_role(unsigned char *smem, const RegTables &tb, const DecodeArgs &a)
 
     // variable pass (ldpc.py:295-311, 321-323): columns (g + q*MB, ic)
     auto variable_pass = [&](const float (&y)[CPT]) {
+        enum { VB = PLANES_VB };                               // columns per batch: loads first, then sums
 #pragma unroll
-        for (int q = 0; q < CPT; ++q) {
-            const int j = g + q * MB;
-            const uint32_t adr = (q < 4 ? cadr0 : cadr1) + (uint32_t)(q & 3) * (MB * Z * CB);
-            const bool p0 = !HOLES || ((cm0 >> j) & 1u), p1 = !HOLES || ((cm1 >> j) & 1u);
-            float acc = 0.0f;
-            if (p0) {
+        for (int q0 = 0; q0 < CPT; q0 += VB) {
+            set_wave_prio(VB < CPT ? 3 - q0 * 3 / (CPT - VB + (VB == CPT)) : 3);
+            float m[VB][4];
+#pragma unroll
+            for (int u = 0; u < VB; ++u) {
+                const int q = q0 + u, j = g + q * MB;
+                const uint32_t adr = (q < 4 ? cadr0 : cadr1) + (uint32_t)(q & 3) * (MB * Z * CB);
+                const bool p0 = !HOLES || ((cm0 >> j) & 1u), p1 = !HOLES || ((cm1 >> j) & 1u);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) m[u][k] = 0.0f;
+                if (p0) { m[u][0] = lds_f32(smem, adr + 4); m[u][1] = lds_f32(smem, adr + 8); }
+                if (p1) { m[u][2] = lds_f32(smem, adr + 12); m[u][3] = lds_f32(smem, adr + 16); }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < VB; ++u) {
+                const int q = q0 + u, j = g + q * MB;
+                const uint32_t adr = (q < 4 ? cadr0 : cadr1) + (uint32_t)(q & 3) * (MB * Z * CB);
+                const bool p0 = !HOLES || ((cm0 >> j) & 1u), p1 = !HOLES || ((cm1 >> j) & 1u);
+                float acc = 0.0f;
                 // first two terms of the column sum: 0 + x + y == x + y == y + x
-                acc = lds_f32(smem, adr + 4) + lds_f32(smem, adr + 8);
-            }
-            if (p1) {
-                const float m10 = lds_f32(smem, adr + 12), m11 = lds_f32(smem, adr + 16);
-                if (p0) {
-                    const bool lo = (lomask >> q) & 1u;
-                    acc = acc + (lo ? m10 : m11);             // lower check index first
-                    acc = acc + (lo ? m11 : m10);
-                } else {
-                    acc = m10 + m11;
+                if (p0) acc = m[u][0] + m[u][1];
+                if (p1) {
+                    if (p0) {
+                        const bool lo = (lomask >> q) & 1u;
+                        acc = acc + (lo ? m[u][2] : m[u][3]);     // lower check index first
+                        acc = acc + (lo ? m[u][3] : m[u][2]);
+                    } else {
+                        acc = m[u][2] + m[u][3];
+                    }
                 }
+                lds_put_f32(smem, adr, acc + y[q]);               // channel last, ldpc.py:322
             }
-            lds_put_f32(smem, adr, acc + y[q]);               // channel last, ldpc.py:322
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -259,7 +305,7 @@ planes_role(unsigned char *smem, const RegTables &tb, const DecodeArgs &a)
 
     for (int64_t frame = blockIdx.x; frame < n_frames; frame += gridDim.x) {
 #ifdef LDPC_TRACE
-        unsigned long long tr[10];
+        unsigned long long tr[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define TRACE(k) tr[k] = clock64()
 #else
 #define TRACE(k)
@@ -284,10 +330,8 @@ planes_role(unsigned char *smem, const RegTables &tb, const DecodeArgs &a)
                     planes_check_pass<Z, CPT, HOLES, B, true>(smem, radr, rmask, D, a.sign_mode, ic);
                 if (synd != 0ull) flags[0] = 1;
             }
-            TRACE(3);
-            lds_barrier();
-            TRACE(4);
-            const int bad = __builtin_amdgcn_readfirstlane(flags[0]);
+                lds_barrier();
+                const int bad = __builtin_amdgcn_readfirstlane(flags[0]);
             if (bad == 0 || a.max_iters <= 0) {
                 my_conv = (bad == 0);
             } else {
@@ -296,12 +340,15 @@ planes_role(unsigned char *smem, const RegTables &tb, const DecodeArgs &a)
                 lds_barrier();
                 for (int it = 1;; ++it) {
                     const int par = it & 1;
+                    if (it == 2) TRACE(3);
                     if (live) {
                         const unsigned long long synd =
                             planes_check_pass<Z, CPT, HOLES, B, false>(smem, radr, rmask, D, a.sign_mode, ic);
                         if (synd != 0ull) flags[par] = 1;
                     }
+                    if (it == 2) TRACE(4);
                     lds_barrier();
+                    if (it == 2) TRACE(5);
                     const int bad2 = __builtin_amdgcn_readfirstlane(flags[par]);   // stop test, ldpc.py:332-335
                     if (bad2 == 0 || it >= a.max_iters) {
                         my_iters = it;
@@ -310,13 +357,15 @@ planes_role(unsigned char *smem, const RegTables &tb, const DecodeArgs &a)
                     }
                     if (tid == 0) flags[par ^ 1] = 0;
                     if (live) variable_pass(y);
+                    if (it == 2) TRACE(6);
                     lds_barrier();
+                    if (it == 2) TRACE(7);
                 }
             }
         }
 
         // ---- hard decisions: 64 consecutive columns per wave and step; lane t keeps step t
-        TRACE(5);
+        TRACE(8);
         unsigned long long mine = 0;
         {
             enum { STEPS = (N + NT - 1) / NT };
@@ -345,15 +394,12 @@ planes_role(unsigned char *smem, const RegTables &tb, const DecodeArgs &a)
             }
 #endif
         }
-        TRACE(6);
 #pragma unroll
         for (int q = 0; q < CPT; ++q) y[q] = ynext[q] * a.llr_scale + 0.0f;
 #ifdef LDPC_TRACE
         asm volatile("" : "+v"(y[0]), "+v"(y[7]));
 #endif
-        TRACE(7);
         lds_barrier();
-        TRACE(8);
         out_bits = mine;
         out_frame = frame;
         out_iters = my_iters;
