@@ -52,17 +52,6 @@ planes_load_frame(const void *llr, int is_f64, int64_t frame_base, uint32_t firs
     }
 }
 
-// s_setprio with a value that is constant only after unrolling
-__device__ __forceinline__ void set_wave_prio(int p)
-{
-    switch (p) {
-    case 0: __builtin_amdgcn_s_setprio(0); break;
-    case 1: __builtin_amdgcn_s_setprio(1); break;
-    case 2: __builtin_amdgcn_s_setprio(2); break;
-    default: __builtin_amdgcn_s_setprio(3); break;
-    }
-}
-
 #ifndef PLANES_CH
 #define PLANES_CH 4                 // edges per pipeline stage of the check pass
 #endif

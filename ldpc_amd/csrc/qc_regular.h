@@ -88,6 +88,17 @@ __device__ __forceinline__ uint32_t opaque(uint32_t x)
     return x;
 }
 
+// s_setprio with a value that is constant only after unrolling
+__device__ __forceinline__ void set_wave_prio(int p)
+{
+    switch (p) {
+    case 0: __builtin_amdgcn_s_setprio(0); break;
+    case 1: __builtin_amdgcn_s_setprio(1); break;
+    case 2: __builtin_amdgcn_s_setprio(2); break;
+    default: __builtin_amdgcn_s_setprio(3); break;
+    }
+}
+
 // LDS-only barrier: waits for this wave's LDS traffic, not for global loads in flight
 // (the next frame's channel values are prefetched across the whole decode of the current one).
 __device__ __forceinline__ void lds_barrier()
@@ -210,12 +221,6 @@ qc_regular_kernel(const RegTables tb, const DecodeArgs a)
             if (live && valid)
                 *reinterpret_cast<T *>(smem + ypost[0] + (uint32_t)q * col_stride) = y[q];
         }
-        {
-            const int64_t fbn = fb + gridDim.x;
-            const int64_t framen = fbn * FPW + f;
-            if (live && fbn < n_fblocks && framen < a.n_frames)
-                load_llr_strided<T, CPT>(a.llr, a.llr_f64, framen * n + g * Z + i, MB * Z, ynext);
-        }
         if (tid < 3 * FPW) flags[tid] = 0;
         if (!chain) { o.min1 = T(0); o.min2 = T(0); o.signs = 0; o.idx = 0; }
         uint32_t act_mask = 0;
@@ -224,6 +229,15 @@ qc_regular_kernel(const RegTables tb, const DecodeArgs a)
             if (fb * FPW + ff < a.n_frames) act_mask |= 1u << ff;
         int my_iters = 0, my_conv = 0;
         lds_barrier();
+        // Next frame's channel values: requested here, not before the barrier.  A CU needs
+        // thousands of cycles to queue a frame's worth of loads; after the barrier that
+        // queueing overlaps the other waves' first check pass instead of idling the CU.
+        {
+            const int64_t fbn = fb + gridDim.x;
+            const int64_t framen = fbn * FPW + f;
+            if (live && fbn < n_fblocks && framen < a.n_frames)
+                load_llr_strided<T, CPT>(a.llr, a.llr_f64, framen * n + g * Z + i, MB * Z, ynext);
+        }
 
         for (int it = 0;; ++it) {
             const bool active = (act_mask >> f) & 1u;
@@ -237,6 +251,8 @@ qc_regular_kernel(const RegTables tb, const DecodeArgs a)
 #pragma unroll
                 for (int c0 = 0; c0 < NS; c0 += CH) {
                     T p[CH];
+                    // waves that are behind get issue priority, so that a SIMD's waves finish together
+                    set_wave_prio(3 - 2 * (c0 / CH));
 #pragma unroll
                     for (int u = 0; u < CH; ++u) {
                         const int s = c0 + u;
@@ -268,6 +284,7 @@ qc_regular_kernel(const RegTables tb, const DecodeArgs a)
                 if (a.sign_mode == LDPC_SIGN_CORRECTED) S ^= (uint32_t)D & 1u;
                 const uint32_t full = D > 0 ? (0xffffffffu << (32 - D)) : 0u;
                 nw.signs = R ^ (S ? full : 0u);
+                set_wave_prio(0);
                 lds_store_state(smem, my_state, nw);
                 if (synd != 0ull) flags[par * FPW + f] = 1;
             }
@@ -295,6 +312,7 @@ qc_regular_kernel(const RegTables tb, const DecodeArgs a)
             if (((act_mask >> f) & 1u) && live) {
 #pragma unroll
                 for (int q0 = 0; q0 < CPT; q0 += 2) {
+                    set_wave_prio(3 - q0 * 3 / (CPT > 2 ? CPT - 2 : 1));
                     StateRaw<T> st[2][MB][W];
 #pragma unroll
                     for (int dq = 0; dq < 2; ++dq)
