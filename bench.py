@@ -68,6 +68,8 @@ def main():
     ap.add_argument('--snr', type=float, default=3.5)
     ap.add_argument('--prec', type=int, default=32, choices=(32, 64))
     ap.add_argument('--max-iters', type=int, default=50)
+    ap.add_argument('--algo', choices=('minsum', 'spa'), default='minsum',
+                    help="'spa' times the sum-product kernel instead (secondary figure, not the headline metric)")
     ap.add_argument('--cpu-frames', type=int, default=262144)
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--seed', type=int, default=460101)
@@ -109,9 +111,13 @@ def main():
     torch.cuda.synchronize()
     t_channel = time.perf_counter() - t0
 
+    spa = args.algo == 'spa'
+    algo = ldpc_amd.ALGO_SUMPRODUCT if spa else ldpc_amd.ALGO_MINSUM
+    llr_scale = 4.0 * 10 ** (args.snr / 10) if spa else 1.0     # sum-product takes 2y/sigma^2
+
     def step():
-        eng.decode_device(llr, F, args.max_iters, prec=args.prec, d_hard=hard, d_iters=iters,
-                          d_conv=conv, d_ones=ones)
+        eng.decode_device(llr, F, args.max_iters, prec=args.prec, algo=algo, llr_scale=llr_scale,
+                          d_hard=hard, d_iters=iters, d_conv=conv, d_ones=ones)
 
     def counters():
         c = torch.stack([torch.tensor(F, device=dev, dtype=torch.int64),
@@ -153,7 +159,7 @@ def main():
         value = K_INFO * total_frames * args.steps / elapsed / 1e9
         k_ms = float(np.mean(kernel_ms))
         achieved = BYTES_PER_FRAME * F / (k_ms * 1e-3) / 1e9
-        info = eng.launch_info(prec=args.prec)
+        info = eng.launch_info(algo=algo, prec=args.prec)
         # HBM bytes per launch from the committed counter passes (rocprofv3 --pmc cannot run
         # inside this process); null for a configuration that was not profiled
         traffic, onchip = None, None
@@ -168,12 +174,15 @@ def main():
             except Exception:
                 traffic, onchip = None, None
         kernel = 'qc_planes_kernel<511, 8, false>' if args.prec == 32 else 'qc_regular_kernel<double, 2, 2, 8, 1, false>'
+        if spa:
+            kernel = 'csr_spa_kernel<float>' if args.prec == 32 else 'csr_spa_kernel<double>'
+            traffic, onchip = None, None
         out = {
-            'metric': 'decoded info Gbit/s, NearEarth (8176,7154) min-sum @50 iters',
+            'metric': 'decoded info Gbit/s, NearEarth (8176,7154) %s @50 iters' % ('sum-product' if spa else 'min-sum'),
             'value': value, 'unit': 'Gbit/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32' if args.prec == 32 else 'f64', 'data': 'synthetic',
-            'config': {'workload': f'NearEarth (8176,7154) min-sum, <=%d iterations with early stop, BPSK/AWGN '
+            'config': {'workload': f'NearEarth (8176,7154) {"sum-product" if spa else "min-sum"}, <=%d iterations with early stop, BPSK/AWGN '
                                    f'%.2f dB (reference SNR definition), %d frames per GPU resident in HBM, '
                                    f'LLR float32 in / packed hard bits + iterations + status out'
                                    % (args.max_iters, args.snr, F),
@@ -196,7 +205,7 @@ def main():
             'frames_per_s': total_frames * args.steps / elapsed,
             'channel_fill_s': t_channel,
         }
-        if not args.no_cpu and world == 1:
+        if not args.no_cpu and world == 1 and not spa:
             ncpu = min(16, os.cpu_count() or 1)
             m = min(args.cpu_frames, F)
             base, it_cpu = cpu_baseline(llr, m, ncpu)

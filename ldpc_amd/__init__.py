@@ -8,6 +8,8 @@ include/ldpc_hip.h).  There is no CPU fallback: decoding without the built
 library or without a HIP device raises.
 """
 from . import codes, common  # noqa: F401
-from .engine import Decoder, LdpcHipError, device_count, library_path  # noqa: F401
+from .engine import (ALGO_MINSUM, ALGO_SUMPRODUCT, COUNTER_FIELDS, SIGN_CORRECTED, SIGN_REFERENCE,  # noqa: F401
+                     Decoder, LdpcHipError, device_count, library_path)
 
-__all__ = ['codes', 'common', 'Decoder', 'LdpcHipError', 'device_count', 'library_path']
+__all__ = ['codes', 'common', 'Decoder', 'LdpcHipError', 'device_count', 'library_path', 'ALGO_MINSUM',
+           'ALGO_SUMPRODUCT', 'SIGN_REFERENCE', 'SIGN_CORRECTED', 'COUNTER_FIELDS']

@@ -527,6 +527,120 @@ csr_minsum_kernel(const CsrTables tb, const DecodeArgs a, unsigned char *workspa
     }
 }
 
+// ---------------------------------------------------------------- sum-product kernel
+// phi(x) = -ln tanh(x/2) = ln((e^x + 1)/(e^x - 1)), its own inverse on x > 0
+__device__ __forceinline__ float spa_phi(float x) { return log1pf(2.0f / expm1f(x)); }
+__device__ __forceinline__ double spa_phi(double x) { return log1p(2.0 / expm1(x)); }
+template <typename T> __device__ __forceinline__ T spa_clamp(T x)
+{
+    // magnitudes entering phi are kept in [1e-12, 80]: phi(1e-12) = 28.3, phi(80) = 3.6e-35 (a normal float)
+    return x < T(1e-12) ? T(1e-12) : (x > T(80) ? T(80) : x);
+}
+
+// Flooding sum-product (tanh rule in the log domain) on an edge list; one frame per
+// workgroup pass.  No counterpart in the reference, whose only check rule is min-sum
+// (ldpc.py:174-202); schedule, polarity, stop test and variable update are the reference's
+// (ldpc.py:282-337).  Per check row, with F_e = phi(clamp|v_e|) accumulated in edge order:
+//     F1 = largest F so far (first wins ties), rest = ordered sum of all the others
+//     exclusive sum of edge e = rest if e holds F1, else (rest - F_e) + F1
+//     |message_e| = phi(clamp(exclusive sum));  signs as in the min-sum kernels.
+// Splitting off the largest term keeps every subtraction well conditioned.
+// post/msg live in LDS when use_lds (n + E values fit), else in this workgroup's slice of
+// `workspace`.  The message slot of an edge holds F_e between the two halves of a check pass.
+template <typename T>
+__global__ void __launch_bounds__(1024)
+csr_spa_kernel(const CsrTables tb, const DecodeArgs a, unsigned char *workspace, size_t ws_stride, int use_lds)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int flags[2];
+    __shared__ int ones_cnt;
+    const int m = tb.m, n = tb.n;
+    T *post = use_lds ? reinterpret_cast<T *>(smem) : reinterpret_cast<T *>(workspace + (size_t)blockIdx.x * ws_stride);
+    T *msg = post + n;
+    const int tid = threadIdx.x;
+    const int nbytes = (n + 7) >> 3;
+
+    for (int64_t frame = blockIdx.x; frame < a.n_frames; frame += gridDim.x) {
+        for (int c = tid; c < n; c += blockDim.x)
+            post[c] = load_llr<T>(a.llr, a.llr_f64, frame * n + c) * T(a.llr_scale) + T(0);
+        for (int e = tid; e < tb.E; e += blockDim.x) msg[e] = T(0);
+        if (tid < 2) flags[tid] = 0;
+        if (tid == 0) ones_cnt = 0;
+        __syncthreads();
+        int it = 0, conv = 0;
+        for (;; ++it) {
+            const int par = it & 1;
+            bool bad_row = false;
+            for (int r = tid; r < m; r += blockDim.x) {
+                const int e0 = tb.row_ptr[r], e1 = tb.row_ptr[r + 1];
+                uint64_t ns = 0;
+                uint32_t sy = 0;
+                T F1 = T(-1), rest = T(0);
+                int arg = -1;
+                for (int e = e0; e < e1; ++e) {
+                    const T p = post[tb.col_idx[e]];
+                    sy ^= (uint32_t)(p > T(0));                      // slicer, ldpc.py:47
+                    const T v = p - msg[e];                          // receive, ldpc.py:161
+                    ns |= (uint64_t)(v < T(0)) << (e - e0);          // sign(0) = +1, ldpc.py:139
+                    const T F = spa_phi(spa_clamp(t_abs(v)));
+                    if (F > F1) {
+                        if (arg >= 0) rest = rest + F1;
+                        F1 = F;
+                        arg = e;
+                    } else {
+                        rest = rest + F;
+                    }
+                    msg[e] = F;
+                }
+                bad_row |= (sy != 0);
+                const int deg = e1 - e0;
+                uint32_t S = parity_of<uint64_t>(ns);
+                if (a.sign_mode == LDPC_SIGN_CORRECTED) S ^= (uint32_t)deg & 1u;
+                for (int e = e0; e < e1; ++e) {
+                    const T x = (e == arg) ? rest : (rest - msg[e]) + F1;
+                    const T mag = spa_phi(spa_clamp(x));
+                    const uint32_t neg = (uint32_t)((ns >> (e - e0)) & 1u) ^ S;
+                    msg[e] = neg ? -mag : mag;
+                }
+            }
+            if (bad_row) flags[par] = 1;
+            __syncthreads();
+            const int bad = flags[par];                              // stop test, ldpc.py:332-335
+            if (bad == 0 || it >= a.max_iters) {
+                conv = (bad == 0);
+                break;
+            }
+            if (tid == 0) flags[par ^ 1] = 0;
+            // variable pass: ordered sum over ascending check index, channel last (ldpc.py:298-303, 322)
+            for (int c = tid; c < n; c += blockDim.x) {
+                T acc = T(0);
+                for (int k = tb.col_ptr[c]; k < tb.col_ptr[c + 1]; ++k)
+                    acc = acc + msg[tb.row_ptr[tb.col_row[k]] + tb.col_e[k]];
+                post[c] = acc + (load_llr<T>(a.llr, a.llr_f64, frame * n + c) * T(a.llr_scale) + T(0));
+            }
+            __syncthreads();
+        }
+        for (int qb = tid; qb < nbytes; qb += blockDim.x) {
+            uint32_t byte = 0;
+            for (int k = 0; k < 8; ++k)
+                if (qb * 8 + k < n) byte |= (uint32_t)(post[qb * 8 + k] > T(0)) << k;
+            if (a.hard) a.hard[frame * nbytes + qb] = (uint8_t)byte;
+            if (byte) atomicAdd(&ones_cnt, (int)__popc(byte));
+        }
+        if (a.soft) {
+            T *so = reinterpret_cast<T *>(a.soft) + frame * n;
+            for (int c = tid; c < n; c += blockDim.x) so[c] = post[c];
+        }
+        __syncthreads();
+        if (tid == 0) {
+            if (a.iters) a.iters[frame] = it;
+            if (a.conv) a.conv[frame] = (uint8_t)conv;
+            if (a.ones) a.ones[frame] = ones_cnt;
+        }
+        __syncthreads();
+    }
+}
+
 // ---------------------------------------------------------------- channel kernel
 __device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k)
 {
@@ -681,7 +795,14 @@ struct Launch {
     const void *fn = nullptr;
     int grid = 0, block = 0, fpw = 1;
     size_t lds = 0;
+    bool spa_lds = false;     // sum-product: posteriors and messages in LDS (else in the workspace)
 };
+
+// posteriors [n] + one message per edge, of the arithmetic type
+static size_t spa_state_bytes(const ldpc_handle *h, int prec)
+{
+    return ((size_t)h->n + (size_t)h->E) * (prec == 64 ? 8 : 4);
+}
 
 template <typename H> static int upload(ldpc_handle *h, const std::vector<H> &v, const H **out)
 {
@@ -731,6 +852,30 @@ extern "C" void ldpc_destroy(ldpc_handle *h)
     for (DevBuf *b : bufs) b->release();
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
+}
+
+// Column-side tables of a row-major edge list (rows ascending => rows ascending inside
+// each column, the order the reference's variable nodes add in, ldpc.py:240-244) and upload.
+static int build_csr(ldpc_handle *h, const std::vector<int32_t> &rp, const std::vector<int32_t> &ci, int m, int n)
+{
+    const int E = rp[m];
+    std::vector<int32_t> cp(n + 1, 0), crow(E), ce(E);
+    for (int e = 0; e < E; ++e) cp[ci[e] + 1]++;
+    for (int c = 0; c < n; ++c) cp[c + 1] += cp[c];
+    std::vector<int32_t> fill(cp.begin(), cp.end() - 1);
+    for (int r = 0; r < m; ++r)
+        for (int e = rp[r]; e < rp[r + 1]; ++e) {
+            const int pos = fill[ci[e]]++;
+            crow[pos] = r;
+            ce[pos] = e - rp[r];
+        }
+    h->csr.m = m; h->csr.n = n; h->csr.E = E;
+    int rc;
+    if ((rc = upload(h, rp, &h->csr.row_ptr)) || (rc = upload(h, ci, &h->csr.col_idx)) ||
+        (rc = upload(h, cp, &h->csr.col_ptr)) || (rc = upload(h, crow, &h->csr.col_row)) ||
+        (rc = upload(h, ce, &h->csr.col_e)))
+        return rc;
+    return 0;
 }
 
 extern "C" int ldpc_create_qc(int device, int Z, int mb, int nb, const int32_t *blk_ptr,
@@ -831,6 +976,26 @@ extern "C" int ldpc_create_qc(int device, int Z, int mb, int nb, const int32_t *
         ldpc_destroy(h);
         return rc;
     }
+    // the same graph as an edge list, columns ascending inside a row (used by the sum-product kernel)
+    {
+        std::vector<int32_t> rp((size_t)h->m + 1, 0), ci;
+        ci.reserve((size_t)h->E);
+        std::vector<int32_t> cols;
+        for (int b = 0; b < mb; ++b)
+            for (int i = 0; i < Z; ++i) {
+                cols.clear();
+                for (int j = 0; j < nb; ++j)
+                    for (int k = blk_ptr[b * nb + j]; k < blk_ptr[b * nb + j + 1]; ++k)
+                        cols.push_back(j * Z + (i + shifts[k]) % Z);
+                std::sort(cols.begin(), cols.end());
+                ci.insert(ci.end(), cols.begin(), cols.end());
+                rp[(size_t)b * Z + i + 1] = (int32_t)ci.size();
+            }
+        if ((rc = build_csr(h, rp, ci, h->m, h->n))) {
+            ldpc_destroy(h);
+            return rc;
+        }
+    }
     *out = h;
     return 0;
 }
@@ -857,26 +1022,13 @@ extern "C" int ldpc_create_csr(int device, int m, int n, const int32_t *row_ptr,
                 return fail(LDPC_E_ARG, "col_idx must be strictly ascending inside a row");
         }
     std::vector<int32_t> rp(row_ptr, row_ptr + m + 1), ci(col_idx, col_idx + E);
-    std::vector<int32_t> cp(n + 1, 0), crow(E), ce(E);
-    for (int e = 0; e < E; ++e) cp[ci[e] + 1]++;
-    for (int c = 0; c < n; ++c) cp[c + 1] += cp[c];
-    std::vector<int32_t> fill(cp.begin(), cp.end() - 1);
-    for (int r = 0; r < m; ++r)          // ascending rows => ascending rows inside each column
-        for (int e = rp[r]; e < rp[r + 1]; ++e) {
-            const int pos = fill[ci[e]]++;
-            crow[pos] = r;
-            ce[pos] = e - rp[r];
-        }
     ldpc_handle *h = new (std::nothrow) ldpc_handle();
     if (!h) return fail(LDPC_E_NOMEM, "out of host memory");
     int rc = open_device(device, h);
     if (rc) { delete h; return rc; }
     h->is_qc = false;
     h->m = m; h->n = n; h->E = E; h->max_row_deg = max_deg;
-    h->csr.m = m; h->csr.n = n; h->csr.E = E;
-    if ((rc = upload(h, rp, &h->csr.row_ptr)) || (rc = upload(h, ci, &h->csr.col_idx)) ||
-        (rc = upload(h, cp, &h->csr.col_ptr)) || (rc = upload(h, crow, &h->csr.col_row)) ||
-        (rc = upload(h, ce, &h->csr.col_e))) {
+    if ((rc = build_csr(h, rp, ci, m, n))) {
         ldpc_destroy(h);
         return rc;
     }
@@ -997,10 +1149,27 @@ static size_t csr_ws_stride(const ldpc_handle *h, int prec)
 
 static int select_launch(ldpc_handle *h, int algo, int prec, int64_t n_frames, bool chained, Launch *L)
 {
-    if (algo != LDPC_ALGO_MINSUM)
-        return fail(LDPC_E_UNSUPPORTED, "algorithm %d is not available in this build", algo);
+    if (algo != LDPC_ALGO_MINSUM && algo != LDPC_ALGO_SUMPRODUCT)
+        return fail(LDPC_E_ARG, "algo must be 0 (min-sum) or 1 (sum-product)");
     if (prec != 32 && prec != 64) return fail(LDPC_E_ARG, "prec must be 32 or 64");
     HIP_TRY(hipSetDevice(h->device));
+    if (algo == LDPC_ALGO_SUMPRODUCT) {
+        if (chained)
+            return fail(LDPC_E_UNSUPPORTED, "the re-used-decoder mode exists for min-sum only");
+        L->fn = prec == 32 ? reinterpret_cast<const void *>(&csr_spa_kernel<float>)
+                           : reinterpret_cast<const void *>(&csr_spa_kernel<double>);
+        L->block = 1024;
+        L->fpw = 1;
+        const size_t need = spa_state_bytes(h, prec);
+        L->spa_lds = need + 64 <= h->lds_max;
+        L->lds = L->spa_lds ? need : 0;
+        if (L->spa_lds) HIP_TRY(hipFuncSetAttribute(L->fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L->lds));
+        int per_cu = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, L->fn, L->block, L->lds));
+        if (per_cu < 1) per_cu = 1;
+        L->grid = (int)std::max<int64_t>(1, std::min<int64_t>(n_frames, (int64_t)h->n_cu * per_cu));
+        return 0;
+    }
     if (h->is_qc) {
         const bool s64 = h->max_row_deg > 32;
         int rc;
@@ -1043,7 +1212,16 @@ static int launch_decode(ldpc_handle *h, int algo, int prec, const DecodeArgs &a
     Launch L;
     int rc = select_launch(h, algo, prec, args.n_frames, args.chain != nullptr, &L);
     if (rc) return rc;
-    if (h->is_qc && h->is_regular) {
+    if (algo == LDPC_ALGO_SUMPRODUCT) {
+        size_t stride = (spa_state_bytes(h, prec) + 255) & ~(size_t)255;
+        if (!L.spa_lds && (rc = h->b_ws.ensure(stride * (size_t)L.grid))) return rc;
+        CsrTables tb = h->csr;
+        DecodeArgs a = args;
+        unsigned char *ws = reinterpret_cast<unsigned char *>(h->b_ws.p);
+        int use_lds = L.spa_lds ? 1 : 0;
+        void *kargs[] = {&tb, &a, &ws, &stride, &use_lds};
+        HIP_TRY(hipLaunchKernel(L.fn, dim3(L.grid), dim3(L.block), kargs, L.lds, h->stream));
+    } else if (h->is_qc && h->is_regular) {
         RegTables tb = h->reg;
         DecodeArgs a = args;
         void *kargs[] = {&tb, &a};
@@ -1248,7 +1426,10 @@ extern "C" int ldpc_eval_awgn(ldpc_handle *h, int algo, int prec, int sign_mode,
                                      reinterpret_cast<int32_t *>(h->b_unc.p))))
                 return rc;
             DecodeArgs a;
-            a.llr = h->b_llr.p; a.llr_f64 = 0; a.llr_scale = 1.0f; a.n_frames = nf;
+            a.llr = h->b_llr.p; a.llr_f64 = 0; a.n_frames = nf;
+            // min-sum works on the raw channel values like the reference (ldpc.py:371-377: no scaling);
+            // sum-product needs true log-likelihood ratios, 2y/sigma^2 for BPSK on AWGN
+            a.llr_scale = algo == LDPC_ALGO_SUMPRODUCT ? (float)(4.0 * pow(10.0, snr_db[s] / 10.0)) : 1.0f;
             a.max_iters = max_iters; a.sign_mode = sign_mode; a.hard = nullptr;
             a.iters = reinterpret_cast<int32_t *>(h->b_iters.p);
             a.conv = reinterpret_cast<uint8_t *>(h->b_conv.p);

@@ -79,18 +79,24 @@ static int f32_syndrome_is_zero(const oracle_graph *g, const float *x) { SYNDROM
 
 #define REAL double
 #define FABS fabs
+#define PHI(x) log1p(2.0 / expm1(x))
 #define FN(name) CAT(f64_, name)
 #include "minsum_impl.h"
+#include "spa_impl.h"
 #undef REAL
 #undef FABS
+#undef PHI
 #undef FN
 
 #define REAL float
 #define FABS fabsf
+#define PHI(x) log1pf(2.0f / expm1f(x))
 #define FN(name) CAT(f32_, name)
 #include "minsum_impl.h"
+#include "spa_impl.h"
 #undef REAL
 #undef FABS
+#undef PHI
 #undef FN
 
 /* Batch drivers.  y: [frames][n]; hard: [frames][n] bytes 0/1 or NULL;
@@ -135,6 +141,47 @@ int oracle_minsum_f32(const oracle_graph *g, int sign_mode, int max_iters, int64
                       float *soft, float *state, int threads)
 {
     BATCH_BODY(float, f32_)
+}
+
+/* Sum-product batch drivers (always a fresh decoder per frame; `state` must be NULL). */
+#define SPA_BATCH_BODY(REAL_T, PFX)                                           \
+    int fail = 0;                                                             \
+    if (state) return -2;                                                     \
+    if (threads <= 0) threads = 1;                                            \
+    _Pragma("omp parallel num_threads(threads)")                              \
+    {                                                                         \
+        REAL_T *c2v = (REAL_T *)malloc(sizeof(REAL_T) * (size_t)(g->E + 1));  \
+        REAL_T *llr = (REAL_T *)malloc(sizeof(REAL_T) * (size_t)(g->n + 1));  \
+        REAL_T *post = (REAL_T *)malloc(sizeof(REAL_T) * (size_t)(g->n + 1)); \
+        if (!c2v || !llr || !post) {                                          \
+            _Pragma("omp atomic write")                                       \
+            fail = 1;                                                         \
+        } else {                                                              \
+            _Pragma("omp for schedule(dynamic, 1)")                           \
+            for (int64_t f = 0; f < n_frames; ++f)                            \
+                PFX##spa_frame(g, sign_mode, max_iters, (REAL_T)llr_scale,    \
+                               y + (size_t)f * g->n,                          \
+                               hard ? hard + (size_t)f * g->n : NULL,         \
+                               iters + f, conv + f,                           \
+                               soft ? soft + (size_t)f * g->n : NULL,         \
+                               c2v, llr, post);                               \
+        }                                                                     \
+        free(c2v); free(llr); free(post);                                     \
+    }                                                                         \
+    return fail ? -1 : 0;
+
+int oracle_spa_f64(const oracle_graph *g, int sign_mode, int max_iters, int64_t n_frames, double llr_scale,
+                   const double *y, uint8_t *hard, int32_t *iters, uint8_t *conv,
+                   double *soft, double *state, int threads)
+{
+    SPA_BATCH_BODY(double, f64_)
+}
+
+int oracle_spa_f32(const oracle_graph *g, int sign_mode, int max_iters, int64_t n_frames, double llr_scale,
+                   const float *y, uint8_t *hard, int32_t *iters, uint8_t *conv,
+                   float *soft, float *state, int threads)
+{
+    SPA_BATCH_BODY(float, f32_)
 }
 
 int oracle_max_threads(void)
