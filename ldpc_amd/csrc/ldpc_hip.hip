@@ -796,6 +796,7 @@ struct Launch {
     int grid = 0, block = 0, fpw = 1;
     size_t lds = 0;
     bool spa_lds = false;     // sum-product: posteriors and messages in LDS (else in the workspace)
+    bool spa_planes = false;  // sum-product on the message-plane kernel
 };
 
 // posteriors [n] + one message per edge, of the arithmetic type
@@ -1120,10 +1121,14 @@ static bool planes_applies(const ldpc_handle *h, int prec, bool chained)
            h->qc.Z == 511 && (size_t)PlanesGeom<511, 8>::LDS_BYTES <= h->lds_max && !(off && off[0] == '1');
 }
 
-static int planes_pick(const ldpc_handle *h, Launch *L)
+static int planes_pick(const ldpc_handle *h, bool spa, Launch *L)
 {
-    L->fn = h->reg_holes ? reinterpret_cast<const void *>(&qc_planes_kernel<511, 8, true>)
-                         : reinterpret_cast<const void *>(&qc_planes_kernel<511, 8, false>);
+    if (spa)
+        L->fn = h->reg_holes ? reinterpret_cast<const void *>(&qc_planes_kernel<511, 8, true, true>)
+                             : reinterpret_cast<const void *>(&qc_planes_kernel<511, 8, false, true>);
+    else
+        L->fn = h->reg_holes ? reinterpret_cast<const void *>(&qc_planes_kernel<511, 8, true, false>)
+                             : reinterpret_cast<const void *>(&qc_planes_kernel<511, 8, false, false>);
     L->block = 2 * PlanesGeom<511, 8>::ZP;
     L->fpw = 1;
     L->lds = PlanesGeom<511, 8>::LDS_BYTES;
@@ -1156,6 +1161,16 @@ static int select_launch(ldpc_handle *h, int algo, int prec, int64_t n_frames, b
     if (algo == LDPC_ALGO_SUMPRODUCT) {
         if (chained)
             return fail(LDPC_E_UNSUPPORTED, "the re-used-decoder mode exists for min-sum only");
+        const char *edge_only = getenv("LDPC_HIP_SPA_EDGE_LIST");
+        if (h->is_qc && planes_applies(h, prec, false) && !(edge_only && edge_only[0] == '1')) {
+            // float32 NearEarth-shaped codes: message planes in LDS, hardware transcendentals
+            int rc = planes_pick(h, true, L);
+            if (rc) return rc;
+            L->spa_planes = true;
+            HIP_TRY(hipFuncSetAttribute(L->fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L->lds));
+            L->grid = (int)std::max<int64_t>(1, std::min<int64_t>(n_frames, (int64_t)h->n_cu));
+            return 0;
+        }
         L->fn = prec == 32 ? reinterpret_cast<const void *>(&csr_spa_kernel<float>)
                            : reinterpret_cast<const void *>(&csr_spa_kernel<double>);
         L->block = 1024;
@@ -1173,7 +1188,7 @@ static int select_launch(ldpc_handle *h, int algo, int prec, int64_t n_frames, b
     if (h->is_qc) {
         const bool s64 = h->max_row_deg > 32;
         int rc;
-        if (planes_applies(h, prec, chained)) rc = planes_pick(h, L);
+        if (planes_applies(h, prec, chained)) rc = planes_pick(h, false, L);
         else if (h->is_regular) rc = prec == 32 ? reg_select<float>(h, chained, L) : reg_select<double>(h, chained, L);
         else if (prec == 32) rc = s64 ? qc_select<float, true>(h, chained, L) : qc_select<float, false>(h, chained, L);
         else            rc = s64 ? qc_select<double, true>(h, chained, L) : qc_select<double, false>(h, chained, L);
@@ -1212,7 +1227,7 @@ static int launch_decode(ldpc_handle *h, int algo, int prec, const DecodeArgs &a
     Launch L;
     int rc = select_launch(h, algo, prec, args.n_frames, args.chain != nullptr, &L);
     if (rc) return rc;
-    if (algo == LDPC_ALGO_SUMPRODUCT) {
+    if (algo == LDPC_ALGO_SUMPRODUCT && !L.spa_planes) {
         size_t stride = (spa_state_bytes(h, prec) + 255) & ~(size_t)255;
         if (!L.spa_lds && (rc = h->b_ws.ensure(stride * (size_t)L.grid))) return rc;
         CsrTables tb = h->csr;

@@ -160,11 +160,111 @@ planes_check_pass(unsigned char *smem, const uint32_t (&radr)[CPT * 4], uint32_t
     return synd;
 }
 
+// phi(x) = -ln tanh(x/2) for x in [1e-12, 80] from the hardware exp2/log2/rcp units, relative
+// error a few 1e-7 (each branch is used where it is well conditioned):
+//   x >= 2        2 atanh(t) as a series in t = e^-x            (log of a number near 1 would lose digits)
+//   x <  2        ln((1 + t) / (1 - t)), with 1 - t from its series below 1/16 (cancellation)
+__device__ __forceinline__ float planes_phi(float x)
+{
+    const float t = __expf(-x);
+    const float t2 = t * t;
+    const float series = (t + t) * (1.0f + t2 * (0.33333334f + t2 * (0.2f + t2 * 0.14285715f)));
+    const float om_small = x * (1.0f - x * (0.5f - x * (0.16666667f - x * (0.041666668f - x * 0.008333334f))));
+    const float om = x < 0.0625f ? om_small : 1.0f - t;
+    const float lg = __logf((1.0f + t) * __frcp_rn(om));
+    return x >= 2.0f ? series : lg;
+}
+
+// Sum-product check pass (the rule stated with csr_spa_kernel): same structure as the min-sum
+// pass; the message slot of an edge holds F_e = phi|v_e| between the two halves.
+template <int Z, int CPT, bool HOLES, int B, bool FIRST>
+__device__ __forceinline__ unsigned long long
+planes_check_pass_spa(unsigned char *smem, const uint32_t (&radr)[CPT * 4], uint32_t rmask, int D, int sign_mode)
+{
+    typedef PlanesGeom<Z, CPT> G;
+    enum { NS = G::NS, CH = 4, NCH = NS / CH };
+    float F1 = 0.0f, rest = 0.0f;          // F > 0 always, so the first edge displaces the initial 0 (rest += 0)
+    uint32_t idx = 0, R = 0;
+    unsigned long long synd = 0;
+    float p[2][CH], c[2][CH];
+#pragma unroll
+    for (int k = -1; k < NCH; ++k) {
+        if (k + 1 < NCH) {
+            const int nb = (k + 1) & 1;
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                const int s = (k + 1) * CH + u;
+                c[nb][u] = 0.0f;
+                if (!HOLES || ((rmask >> (s >> 1)) & 1u)) {
+                    p[nb][u] = lds_f32(smem, radr[s]);
+                    if (!FIRST) c[nb][u] = lds_f32(smem, radr[s] + 4u * (1 + 2 * B + (s & 1)));
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (k < 0) continue;
+        if (k * CH % 8 == 0) set_wave_prio(3 - (k * CH / 8) * 3 / (NS / 8 - 1));
+        const int cb = k & 1;
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            const int s = k * CH + u;
+            if (!HOLES || ((rmask >> (s >> 1)) & 1u)) {
+                synd ^= __ballot(p[cb][u] > 0.0f);
+                const float v = FIRST ? p[cb][u] : p[cb][u] - c[cb][u];
+                R = __builtin_amdgcn_alignbit(R, __float_as_uint(v), 31);
+                const float F = planes_phi(__builtin_amdgcn_fmed3f(fabsf(v), 1e-12f, 80.0f));
+                lds_put_f32(smem, radr[s] + 4u * (1 + 2 * B + (s & 1)), F);
+                const bool gt = F > F1;
+                rest = rest + (gt ? F1 : F);
+                idx = gt ? (uint32_t)s : idx;
+                F1 = gt ? F : F1;
+            }
+        }
+        asm volatile("" : "+v"(F1), "+v"(rest), "+v"(idx), "+v"(R), "+s"(synd));
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (D < 32) R = D > 0 ? (R << (32 - D)) : 0u;
+    uint32_t S = __popc(R) & 1u;
+    if (sign_mode == LDPC_SIGN_CORRECTED) S ^= (uint32_t)D & 1u;
+    const uint32_t full = D > 0 ? (0xffffffffu << (32 - D)) : 0u;
+    const uint32_t T = R ^ (S ? full : 0u);
+    set_wave_prio(0);
+    float f[2][CH];
+#pragma unroll
+    for (int k = -1; k < NCH; ++k) {
+        if (k + 1 < NCH) {
+            const int nb = (k + 1) & 1;
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                const int s = (k + 1) * CH + u;
+                f[nb][u] = 0.0f;
+                if (!HOLES || ((rmask >> (s >> 1)) & 1u))
+                    f[nb][u] = lds_f32(smem, radr[s] + 4u * (1 + 2 * B + (s & 1)));
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (k < 0) continue;
+        const int cb = k & 1;
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            const int s = k * CH + u;
+            if (!HOLES || ((rmask >> (s >> 1)) & 1u)) {
+                const uint32_t rank = HOLES ? (uint32_t)(__popc(rmask & ((1u << (s >> 1)) - 1u)) * 2 + (s & 1)) : (uint32_t)s;
+                const float x = idx == (uint32_t)s ? rest : (rest - f[cb][u]) + F1;
+                const float mag = planes_phi(__builtin_amdgcn_fmed3f(x, 1e-12f, 80.0f));
+                lds_put_u32(smem, radr[s] + 4u * (1 + 2 * B + (s & 1)), __float_as_uint(mag) | ((T << rank) & 0x80000000u));
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    return synd;
+}
+
 // The whole decode loop for the threads of block-row / column-group B.  It is instantiated
 // once per B and the kernel branches ONCE (wave-uniformly) into its copy: with one shared
 // loop and a branch per pass the optimiser merges the common tails of the copies and
 // carries every per-edge intermediate across the merge in registers.
-template <int Z, int CPT, bool HOLES, int B>
+template <int Z, int CPT, bool HOLES, int B, bool SPA>
 __device__ __forceinline__ void
 planes_role(unsigned char *smem, const RegTables &tb, const DecodeArgs &a)
 {
@@ -315,8 +415,9 @@ planes_role(unsigned char *smem, const RegTables &tb, const DecodeArgs &a)
         // ---- iteration 0 is peeled: its check pass has no previous messages to read
         {
             if (live) {
-                const unsigned long long synd =
-                    planes_check_pass<Z, CPT, HOLES, B, true>(smem, radr, rmask, D, a.sign_mode, ic);
+                const unsigned long long synd = SPA
+                    ? planes_check_pass_spa<Z, CPT, HOLES, B, true>(smem, radr, rmask, D, a.sign_mode)
+                    : planes_check_pass<Z, CPT, HOLES, B, true>(smem, radr, rmask, D, a.sign_mode, ic);
                 if (synd != 0ull) flags[0] = 1;
             }
                 lds_barrier();
@@ -331,8 +432,9 @@ planes_role(unsigned char *smem, const RegTables &tb, const DecodeArgs &a)
                     const int par = it & 1;
                     if (it == 2) TRACE(3);
                     if (live) {
-                        const unsigned long long synd =
-                            planes_check_pass<Z, CPT, HOLES, B, false>(smem, radr, rmask, D, a.sign_mode, ic);
+                        const unsigned long long synd = SPA
+                            ? planes_check_pass_spa<Z, CPT, HOLES, B, false>(smem, radr, rmask, D, a.sign_mode)
+                            : planes_check_pass<Z, CPT, HOLES, B, false>(smem, radr, rmask, D, a.sign_mode, ic);
                         if (synd != 0ull) flags[par] = 1;
                     }
                     if (it == 2) TRACE(4);
@@ -404,13 +506,13 @@ planes_role(unsigned char *smem, const RegTables &tb, const DecodeArgs &a)
     flush_outputs();
 }
 
-template <int Z, int CPT, bool HOLES>
+template <int Z, int CPT, bool HOLES, bool SPA>
 __global__ void __launch_bounds__(1024)
 qc_planes_kernel(const RegTables tb, const DecodeArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (__builtin_amdgcn_readfirstlane(threadIdx.x / PlanesGeom<Z, CPT>::ZP) == 0)
-        planes_role<Z, CPT, HOLES, 0>(smem, tb, a);
+        planes_role<Z, CPT, HOLES, 0, SPA>(smem, tb, a);
     else
-        planes_role<Z, CPT, HOLES, 1>(smem, tb, a);
+        planes_role<Z, CPT, HOLES, 1, SPA>(smem, tb, a);
 }

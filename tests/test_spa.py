@@ -135,3 +135,27 @@ def test_gpu_spa_sweep_and_corrected_sign():
         llr = y * np.float32(4 * 10 ** 0.6)
         good = eng.decode(llr, 50, prec=32, algo=ldpc_amd.ALGO_SUMPRODUCT, sign_mode=ldpc_amd.SIGN_CORRECTED)
         assert good['converged'].all() and good['hard'].sum() == 0
+
+
+@pytest.mark.gpu
+def test_gpu_spa_edge_list_kernel_on_near_earth(oracle_mod, monkeypatch):
+    """float32 NearEarth normally takes the message-plane kernel; the edge-list kernel
+    (exact log1p/expm1 of the device math library) must agree with it and with the CPU."""
+    import ldpc_amd
+    qc, H = build_code('nearEarth')
+    orc = oracle_mod.Oracle(H)
+    y = make_llrs(31, 3.3, H.shape[1], 24)
+    scale = 4 * 10 ** 0.33
+    hard, iters, conv, _ = orc.spa(y, scale, 50, prec=32, want_soft=False, threads=8)
+    llr = y * np.float32(scale)
+    with ldpc_amd.Decoder(qc) as eng:
+        fast = eng.decode(llr, 50, prec=32, algo=ldpc_amd.ALGO_SUMPRODUCT)
+        assert eng.launch_info(algo=ldpc_amd.ALGO_SUMPRODUCT, prec=32)['lds_bytes'] == 163792
+        monkeypatch.setenv('LDPC_HIP_SPA_EDGE_LIST', '1')
+        slow = eng.decode(llr, 50, prec=32, algo=ldpc_amd.ALGO_SUMPRODUCT)
+        assert eng.launch_info(algo=ldpc_amd.ALGO_SUMPRODUCT, prec=32)['lds_bytes'] == 163520
+    cv = conv == 1
+    assert cv.sum() >= 20
+    for r in (fast, slow):
+        assert np.array_equal(r['iters'][cv], iters[cv]) and np.array_equal(r['hard'][cv], hard[cv])
+        assert np.array_equal(r['converged'][cv], conv[cv])
