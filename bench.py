@@ -177,6 +177,29 @@ def main():
         if spa:
             kernel = 'csr_spa_kernel<float>' if args.prec == 32 else 'csr_spa_kernel<double>'
             traffic, onchip = None, None
+        # on-chip roofline of the float32 min-sum kernel: LDS bytes it must move per frame-iteration
+        # (16 B per edge + 4 B per column + 8 B per row) against 256 CUs x 128 B/clk x 2.4 GHz
+        mean_iters = float(c[3]) / total_frames
+        lds = None
+        if args.prec == 32 and not spa:
+            lds_bytes_iter = 16 * 32704 + 4 * N_CODE + 8 * 1022
+            # one check pass more than iterations per frame (the pass that finds the syndrome zero / the budget spent)
+            lds_rate = lds_bytes_iter * (mean_iters + 0.75) * F / (k_ms * 1e-3) / 1e12
+            lds = {'bound': 'lds', 'achieved': lds_rate, 'peak': 256 * 128 * 2.4e9 / 1e12, 'unit': 'TB/s',
+                   'frac': lds_rate / (256 * 128 * 2.4e9 / 1e12), 'bytes_per_frame_iteration': lds_bytes_iter}
+        # forced 50 iterations (no frame converges at 0 dB): the per-iteration rate without early stop
+        Ff = min(F, 65536)
+        eng.channel_awgn_device(llr[:Ff], Ff, 0.0, seed=args.seed + 1, first_frame=0)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        eng.decode_device(llr, Ff, args.max_iters, prec=args.prec, algo=algo, llr_scale=4.0 if spa else 1.0,
+                          d_hard=hard, d_iters=iters, d_conv=conv, d_ones=ones)
+        e1.record(stream)
+        torch.cuda.synchronize()
+        fixed_ms = e0.elapsed_time(e1)
+        fixed_iters = float(iters[:Ff].float().mean())
+        eng.channel_awgn_device(llr[:Ff], Ff, args.snr, seed=args.seed, first_frame=rank * F)   # restore the batch
+        torch.cuda.synchronize()
         out = {
             'metric': 'decoded info Gbit/s, NearEarth (8176,7154) %s @50 iters' % ('sum-product' if spa else 'min-sum'),
             'value': value, 'unit': 'Gbit/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -196,7 +219,10 @@ def main():
                                  'results-out, so the HBM fraction is small by design.  The kernel is bound by '
                                  'vector-instruction issue and LDS bandwidth (onchip: busy fractions from the '
                                  'committed counter passes)'},
-            'stats': {'frames': total_frames, 'mean_iters': float(c[3]) / total_frames,
+            'roofline_lds': lds,
+            'fixed_iterations': {'info_gbps': K_INFO * Ff / (fixed_ms * 1e-3) / 1e9, 'frames': Ff, 'snr_db': 0.0,
+                                 'mean_iters': fixed_iters, 'kernel_ms': fixed_ms},
+            'stats': {'frames': total_frames, 'mean_iters': mean_iters,
                       'fer': float(c[1]) / total_frames, 'ber': float(c[2]) / (total_frames * N_CODE),
                       'uncoded_ber': float(c[4]) / (total_frames * N_CODE),
                       'not_codeword': int(c[5])},
