@@ -183,3 +183,16 @@ def parse_hot_position_file(path, dim0, dim1, Z):
     blocks = [[tuple(sorted(set(int(t) for t in lines[b * nb + j].split(',') if t.strip() != '')))
                for j in range(nb)] for b in range(mb)]
     return QCCode(Z, blocks)
+
+
+def observation_to_qc(compressedMatrix):
+    """The gym observation (2048 bytes) as a QCCode, without building the dense matrix.
+    common.uncompress (common.py:349-365) turns every 511-bit segment into a circulant whose
+    first COLUMN is the segment, so a hot position `loc` of the segment is the shift
+    (-loc) mod 511 of this module's convention (row i has its ones at (i + shift) mod Z)."""
+    from .common import observation_to_first_columns
+    top = observation_to_first_columns(compressedMatrix)
+    Z = 511
+    blocks = [[sorted(int((-loc) % Z) for loc in np.flatnonzero(top[b][j * Z:(j + 1) * Z]))
+               for j in range(16)] for b in range(2)]
+    return QCCode(Z, blocks)

@@ -101,3 +101,51 @@ def recursiveLinearFit(xData, yData, numberOfIterations=10, earlyStopping=False)
         snr = snr[trendP(snr) > 0]
         itr += 1
     return snr, ber, p, trendP, itr
+
+
+# ---------------------------------------------------------------------------
+# The gym environment's observation format: rows 0 and 511 of the 1022 x 8176 parity matrix,
+# each padded to 8192 bits (one zero after every 511) and packed to 1024 bytes.
+_OBS_Z = 511
+_OBS_BLOCKS = 16
+
+
+def _observation_mask():
+    mask = np.ones(8192, dtype=bool)
+    mask[(np.arange(_OBS_BLOCKS) + 1) * (_OBS_Z + 1) - 1] = False       # common.py:352-354
+    return mask
+
+
+def observation_to_first_columns(compressedMatrix):
+    """The two unpadded 8176-bit vectors of an observation (common.py:355-359)."""
+    c = np.asarray(compressedMatrix, dtype=np.uint8)
+    half = len(c) // 2
+    mask = _observation_mask()
+    return np.unpackbits(c[:half])[mask], np.unpackbits(c[half:])[mask]
+
+
+def uncompress(compressedMatrix):
+    """Observation -> dense int32 parity matrix, as the reference does it (common.py:349-365):
+    every 511-bit segment becomes scipy.linalg.circulant(segment), i.e. the segment is the
+    block's first COLUMN (M[i, j] = segment[(i - j) mod 511]), not its first row."""
+    top = observation_to_first_columns(compressedMatrix)
+    Z = _OBS_Z
+    H = np.zeros((2 * Z, _OBS_BLOCKS * Z), dtype=np.int32)
+    i = np.arange(Z)
+    for b in range(2):
+        for j in range(_OBS_BLOCKS):
+            for loc in np.flatnonzero(top[b][j * Z:(j + 1) * Z]):
+                H[b * Z + i, j * Z + (i - loc) % Z] = 1
+    return H
+
+
+def compress(H):
+    """Dense parity matrix -> observation (LdpcEnv.compress, ldpc_env.py:379-393): rows 0 and 511."""
+    H = np.asarray(H)
+    mask = _observation_mask()
+    out = []
+    for r in (0, _OBS_Z):
+        padded = np.zeros(8192, dtype=np.uint8)
+        padded[mask] = H[r, :] != 0
+        out.append(np.packbits(padded))
+    return np.hstack(out)
