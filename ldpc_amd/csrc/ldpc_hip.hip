@@ -1123,12 +1123,8 @@ static bool planes_applies(const ldpc_handle *h, int prec, bool chained)
 
 static int planes_pick(const ldpc_handle *h, bool spa, Launch *L)
 {
-    if (spa)
-        L->fn = h->reg_holes ? reinterpret_cast<const void *>(&qc_planes_kernel<511, 8, true, true>)
-                             : reinterpret_cast<const void *>(&qc_planes_kernel<511, 8, false, true>);
-    else
-        L->fn = h->reg_holes ? reinterpret_cast<const void *>(&qc_planes_kernel<511, 8, true, false>)
-                             : reinterpret_cast<const void *>(&qc_planes_kernel<511, 8, false, false>);
+    L->fn = spa ? reinterpret_cast<const void *>(&qc_planes_kernel<511, 8, true>)
+                : reinterpret_cast<const void *>(&qc_planes_kernel<511, 8, false>);
     L->block = 2 * PlanesGeom<511, 8>::ZP;
     L->fpw = 1;
     L->lds = PlanesGeom<511, 8>::LDS_BYTES;

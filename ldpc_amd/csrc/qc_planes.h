@@ -18,6 +18,12 @@
 //   variable pass, per column: 4 LDS reads, 5 additions, 1 LDS write.
 // Same arithmetic in the same order as the other kernels (ldpc.py:150-163,
 // 174-202, 295-324): results are bit-identical.
+//
+// Zeroed circulants (the variants of testMatricesGeneratorScript.py:23-34) run the same
+// code: the two edges a row loses point to one dummy record whose posterior is +inf.  Such
+// an edge has |v| = inf (never a minimum), sign + and hard decision 1 -- twice per row, so
+// the parity is untouched; what the row writes back lands in the dummy's message slots.
+// The message slots no check owns any more are zeroed once per launch and add +0.
 #pragma once
 
 __device__ __forceinline__ float lds_f32(const unsigned char *smem, uint32_t addr)
@@ -64,15 +70,17 @@ struct PlanesGeom {
     enum { MB = 2, W = 2, NB = CPT * MB, NS = NB * W, N = NB * Z, ZP = (Z + 63) / 64 * 64,
            CB = 20,                                  // bytes per column record
            REC_BYTES = N * CB, SHTAB_OFF = REC_BYTES, SHTAB_BYTES = MB * NB * W * 4,
-           FLAG_OFF = SHTAB_OFF + SHTAB_BYTES, LDS_BYTES = FLAG_OFF + 16 };
+           FLAG_OFF = SHTAB_OFF + SHTAB_BYTES,
+           DUMMY_OFF = FLAG_OFF + 16,                // record every edge of a zeroed circulant points to
+           LDS_BYTES = (DUMMY_OFF + CB + 15) / 16 * 16 };
 };
 
 // Check pass of one row of block-row B.  FIRST: the row's previous messages are all +0
 // (fresh decoder, checkNode.__init__ ldpc.py:121) and are not read.  Returns the lanes
 // whose parity check on the current hard decisions fails.
-template <int Z, int CPT, bool HOLES, int B, bool FIRST>
+template <int Z, int CPT, int B, bool FIRST>
 __device__ __forceinline__ unsigned long long
-planes_check_pass(unsigned char *smem, const uint32_t (&radr)[CPT * 4], uint32_t rmask, int D, int sign_mode, int ic)
+planes_check_pass(unsigned char *smem, const uint32_t (&radr)[CPT * 4], int D, int sign_mode, int ic)
 {
     typedef PlanesGeom<Z, CPT> G;
     enum { NS = G::NS, CH = PLANES_CH, NCH = NS / CH };
@@ -92,7 +100,7 @@ planes_check_pass(unsigned char *smem, const uint32_t (&radr)[CPT * 4], uint32_t
             for (int u = 0; u < CH; ++u) {
                 const int s = (k + 1) * CH + u;
                 c[nb][u] = 0.0f;
-                if (!HOLES || ((rmask >> (s >> 1)) & 1u)) {
+                {
                     p[nb][u] = lds_f32(smem, radr[s]);
                     if (!FIRST) c[nb][u] = lds_f32(smem, radr[s] + 4u * (1 + 2 * B + (s & 1)));
                 }
@@ -109,7 +117,7 @@ planes_check_pass(unsigned char *smem, const uint32_t (&radr)[CPT * 4], uint32_t
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
             const int s = k * CH + u;
-            if (!HOLES || ((rmask >> (s >> 1)) & 1u)) {
+            {
                 synd ^= __ballot(p[cb][u] > 0.0f);                          // slicer, ldpc.py:47
                 const float v = FIRST ? p[cb][u] : p[cb][u] - c[cb][u];     // receive, ldpc.py:161 (x - 0 == x)
                 R = __builtin_amdgcn_alignbit(R, __float_as_uint(v), 31);   // (R << 1) | sign(v), ldpc.py:139
@@ -131,10 +139,10 @@ planes_check_pass(unsigned char *smem, const uint32_t (&radr)[CPT * 4], uint32_t
     }
     // R: D sign bits, first edge highest.  Left-align and fold in the product of all signs:
     // a bit of T is then the sign of the outgoing message itself (ldpc.py:190)
-    if (D < 32) R = D > 0 ? (R << (32 - D)) : 0u;
+    if (NS < 32) R <<= (32 - NS);
     uint32_t S = __popc(R) & 1u;
-    if (sign_mode == LDPC_SIGN_CORRECTED) S ^= (uint32_t)D & 1u;
-    const uint32_t full = D > 0 ? (0xffffffffu << (32 - D)) : 0u;
+    if (sign_mode == LDPC_SIGN_CORRECTED) S ^= (uint32_t)D & 1u;       // D: the row's real degree
+    const uint32_t full = 0xffffffffu << (32 - NS);
     const uint32_t T = R ^ (S ? full : 0u);
     const uint32_t m1 = __float_as_uint(min1), m2 = __float_as_uint(min2);
     // shift of the arg-min edge, needed after the loop below (idx differs from lane to lane)
@@ -143,8 +151,8 @@ planes_check_pass(unsigned char *smem, const uint32_t (&radr)[CPT * 4], uint32_t
     // every edge gets +-min1 ...
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-        if (!HOLES || ((rmask >> (s >> 1)) & 1u)) {
-            const uint32_t rank = HOLES ? (uint32_t)(__popc(rmask & ((1u << (s >> 1)) - 1u)) * 2 + (s & 1)) : (uint32_t)s;
+        {
+            const uint32_t rank = (uint32_t)s;
             lds_put_u32(smem, radr[s] + 4u * (1 + 2 * B + (s & 1)), m1 | ((T << rank) & 0x80000000u));
         }
         if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
@@ -154,8 +162,8 @@ planes_check_pass(unsigned char *smem, const uint32_t (&radr)[CPT * 4], uint32_t
         int ci = ic + esh;
         ci = ci >= Z ? ci - Z : ci;
         const uint32_t adr = (uint32_t)(ej * Z + ci) * G::CB + 4u * (1 + 2 * B) + 4u * ek;
-        const uint32_t rank = HOLES ? (uint32_t)__popc(rmask & ((1u << ej) - 1u)) * 2 + ek : idx;
-        if (D > 0) lds_put_u32(smem, adr, m2 | ((T << rank) & 0x80000000u));
+        const uint32_t rank = idx;
+        if (D > 0) lds_put_u32(smem, adr, m2 | ((T << rank) & 0x80000000u));     // D == 0: every edge is a dummy
     }
     return synd;
 }
@@ -177,9 +185,9 @@ __device__ __forceinline__ float planes_phi(float x)
 
 // Sum-product check pass (the rule stated with csr_spa_kernel): same structure as the min-sum
 // pass; the message slot of an edge holds F_e = phi|v_e| between the two halves.
-template <int Z, int CPT, bool HOLES, int B, bool FIRST>
+template <int Z, int CPT, int B, bool FIRST>
 __device__ __forceinline__ unsigned long long
-planes_check_pass_spa(unsigned char *smem, const uint32_t (&radr)[CPT * 4], uint32_t rmask, int D, int sign_mode)
+planes_check_pass_spa(unsigned char *smem, const uint32_t (&radr)[CPT * 4], int D, int sign_mode)
 {
     typedef PlanesGeom<Z, CPT> G;
     enum { NS = G::NS, CH = 4, NCH = NS / CH };
@@ -195,7 +203,7 @@ planes_check_pass_spa(unsigned char *smem, const uint32_t (&radr)[CPT * 4], uint
             for (int u = 0; u < CH; ++u) {
                 const int s = (k + 1) * CH + u;
                 c[nb][u] = 0.0f;
-                if (!HOLES || ((rmask >> (s >> 1)) & 1u)) {
+                {
                     p[nb][u] = lds_f32(smem, radr[s]);
                     if (!FIRST) c[nb][u] = lds_f32(smem, radr[s] + 4u * (1 + 2 * B + (s & 1)));
                 }
@@ -208,11 +216,13 @@ planes_check_pass_spa(unsigned char *smem, const uint32_t (&radr)[CPT * 4], uint
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
             const int s = k * CH + u;
-            if (!HOLES || ((rmask >> (s >> 1)) & 1u)) {
+            {
                 synd ^= __ballot(p[cb][u] > 0.0f);
                 const float v = FIRST ? p[cb][u] : p[cb][u] - c[cb][u];
                 R = __builtin_amdgcn_alignbit(R, __float_as_uint(v), 31);
-                const float F = planes_phi(__builtin_amdgcn_fmed3f(fabsf(v), 1e-12f, 80.0f));
+                const float av = fabsf(v);
+                float F = planes_phi(__builtin_amdgcn_fmed3f(av, 1e-12f, 80.0f));
+                F = av == __uint_as_float(0x7f800000u) ? 0.0f : F;          // edge of a zeroed circulant: no term
                 lds_put_f32(smem, radr[s] + 4u * (1 + 2 * B + (s & 1)), F);
                 const bool gt = F > F1;
                 rest = rest + (gt ? F1 : F);
@@ -223,10 +233,10 @@ planes_check_pass_spa(unsigned char *smem, const uint32_t (&radr)[CPT * 4], uint
         asm volatile("" : "+v"(F1), "+v"(rest), "+v"(idx), "+v"(R), "+s"(synd));
         __builtin_amdgcn_sched_barrier(0);
     }
-    if (D < 32) R = D > 0 ? (R << (32 - D)) : 0u;
+    if (NS < 32) R <<= (32 - NS);
     uint32_t S = __popc(R) & 1u;
-    if (sign_mode == LDPC_SIGN_CORRECTED) S ^= (uint32_t)D & 1u;
-    const uint32_t full = D > 0 ? (0xffffffffu << (32 - D)) : 0u;
+    if (sign_mode == LDPC_SIGN_CORRECTED) S ^= (uint32_t)D & 1u;       // D: the row's real degree
+    const uint32_t full = 0xffffffffu << (32 - NS);
     const uint32_t T = R ^ (S ? full : 0u);
     set_wave_prio(0);
     float f[2][CH];
@@ -238,8 +248,7 @@ planes_check_pass_spa(unsigned char *smem, const uint32_t (&radr)[CPT * 4], uint
             for (int u = 0; u < CH; ++u) {
                 const int s = (k + 1) * CH + u;
                 f[nb][u] = 0.0f;
-                if (!HOLES || ((rmask >> (s >> 1)) & 1u))
-                    f[nb][u] = lds_f32(smem, radr[s] + 4u * (1 + 2 * B + (s & 1)));
+                f[nb][u] = lds_f32(smem, radr[s] + 4u * (1 + 2 * B + (s & 1)));
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -248,8 +257,8 @@ planes_check_pass_spa(unsigned char *smem, const uint32_t (&radr)[CPT * 4], uint
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
             const int s = k * CH + u;
-            if (!HOLES || ((rmask >> (s >> 1)) & 1u)) {
-                const uint32_t rank = HOLES ? (uint32_t)(__popc(rmask & ((1u << (s >> 1)) - 1u)) * 2 + (s & 1)) : (uint32_t)s;
+            {
+                const uint32_t rank = (uint32_t)s;
                 const float x = idx == (uint32_t)s ? rest : (rest - f[cb][u]) + F1;
                 const float mag = planes_phi(__builtin_amdgcn_fmed3f(x, 1e-12f, 80.0f));
                 lds_put_u32(smem, radr[s] + 4u * (1 + 2 * B + (s & 1)), __float_as_uint(mag) | ((T << rank) & 0x80000000u));
@@ -264,7 +273,7 @@ planes_check_pass_spa(unsigned char *smem, const uint32_t (&radr)[CPT * 4], uint
 // once per B and the kernel branches ONCE (wave-uniformly) into its copy: with one shared
 // loop and a branch per pass the optimiser merges the common tails of the copies and
 // carries every per-edge intermediate across the merge in registers.
-template <int Z, int CPT, bool HOLES, int B, bool SPA>
+template <int Z, int CPT, int B, bool SPA>
 __device__ __forceinline__ void
 planes_role(unsigned char *smem, const RegTables &tb, const DecodeArgs &a)
 {
@@ -286,10 +295,13 @@ planes_role(unsigned char *smem, const RegTables &tb, const DecodeArgs &a)
 
     // ---- per-launch set-up
     for (int x = tid; x < MB * NB * W; x += NT) shtab[x] = tb.shifts[x];
-    uint32_t rmask = g == 0 ? tb.row_mask[0] : tb.row_mask[1];
-    if (!HOLES) rmask = (1u << NB) - 1u;
-    const uint32_t cm0 = HOLES ? tb.row_mask[0] : rmask, cm1 = HOLES ? tb.row_mask[1] : rmask;
+    const uint32_t rmask = g == 0 ? tb.row_mask[0] : tb.row_mask[1];     // present circulants of my block-row
     const int D = __popc(rmask) * W;
+    // once per launch: message slots (those of zeroed circulants are never written again) and the dummy record
+    for (int x = tid; x < N; x += NT)
+#pragma unroll
+        for (int k = 1; k <= 4; ++k) lds_put_f32(smem, (uint32_t)x * CB + 4u * k, 0.0f);
+    if (tid < 5) lds_put_u32(smem, G::DUMMY_OFF + 4u * tid, tid == 0 ? 0x7f800000u : 0u);
     uint32_t radr[NS];                       // record address of the column each of my row's edges goes to
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
@@ -297,7 +309,7 @@ planes_role(unsigned char *smem, const RegTables &tb, const DecodeArgs &a)
         int c = ic + sh;
         c = c >= Z ? c - Z : c;
         // laundered: otherwise the per-block constant is split off and re-added at every use
-        radr[s] = opaque((uint32_t)((s >> 1) * Z + c) * CB);
+        radr[s] = opaque(((rmask >> (s >> 1)) & 1u) ? (uint32_t)((s >> 1) * Z + c) * CB : (uint32_t)G::DUMMY_OFF);
     }
     // my columns: block-column g + q*MB, position ic; records q and q+4 share a base register
     const uint32_t cadr0 = (uint32_t)(g * Z + ic) * CB;
@@ -320,32 +332,21 @@ planes_role(unsigned char *smem, const RegTables &tb, const DecodeArgs &a)
             float m[VB][4];
 #pragma unroll
             for (int u = 0; u < VB; ++u) {
-                const int q = q0 + u, j = g + q * MB;
+                const int q = q0 + u;
                 const uint32_t adr = (q < 4 ? cadr0 : cadr1) + (uint32_t)(q & 3) * (MB * Z * CB);
-                const bool p0 = !HOLES || ((cm0 >> j) & 1u), p1 = !HOLES || ((cm1 >> j) & 1u);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) m[u][k] = 0.0f;
-                if (p0) { m[u][0] = lds_f32(smem, adr + 4); m[u][1] = lds_f32(smem, adr + 8); }
-                if (p1) { m[u][2] = lds_f32(smem, adr + 12); m[u][3] = lds_f32(smem, adr + 16); }
+                for (int k = 0; k < 4; ++k) m[u][k] = lds_f32(smem, adr + 4u * (k + 1));
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int u = 0; u < VB; ++u) {
-                const int q = q0 + u, j = g + q * MB;
+                const int q = q0 + u;
                 const uint32_t adr = (q < 4 ? cadr0 : cadr1) + (uint32_t)(q & 3) * (MB * Z * CB);
-                const bool p0 = !HOLES || ((cm0 >> j) & 1u), p1 = !HOLES || ((cm1 >> j) & 1u);
-                float acc = 0.0f;
                 // first two terms of the column sum: 0 + x + y == x + y == y + x
-                if (p0) acc = m[u][0] + m[u][1];
-                if (p1) {
-                    if (p0) {
-                        const bool lo = (lomask >> q) & 1u;
-                        acc = acc + (lo ? m[u][2] : m[u][3]);     // lower check index first
-                        acc = acc + (lo ? m[u][3] : m[u][2]);
-                    } else {
-                        acc = m[u][2] + m[u][3];
-                    }
-                }
+                float acc = m[u][0] + m[u][1];
+                const bool lo = (lomask >> q) & 1u;
+                acc = acc + (lo ? m[u][2] : m[u][3]);             // lower check index first
+                acc = acc + (lo ? m[u][3] : m[u][2]);
                 lds_put_f32(smem, adr, acc + y[q]);               // channel last, ldpc.py:322
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -416,8 +417,8 @@ planes_role(unsigned char *smem, const RegTables &tb, const DecodeArgs &a)
         {
             if (live) {
                 const unsigned long long synd = SPA
-                    ? planes_check_pass_spa<Z, CPT, HOLES, B, true>(smem, radr, rmask, D, a.sign_mode)
-                    : planes_check_pass<Z, CPT, HOLES, B, true>(smem, radr, rmask, D, a.sign_mode, ic);
+                    ? planes_check_pass_spa<Z, CPT, B, true>(smem, radr, D, a.sign_mode)
+                    : planes_check_pass<Z, CPT, B, true>(smem, radr, D, a.sign_mode, ic);
                 if (synd != 0ull) flags[0] = 1;
             }
                 lds_barrier();
@@ -433,8 +434,8 @@ planes_role(unsigned char *smem, const RegTables &tb, const DecodeArgs &a)
                     if (it == 2) TRACE(3);
                     if (live) {
                         const unsigned long long synd = SPA
-                            ? planes_check_pass_spa<Z, CPT, HOLES, B, false>(smem, radr, rmask, D, a.sign_mode)
-                            : planes_check_pass<Z, CPT, HOLES, B, false>(smem, radr, rmask, D, a.sign_mode, ic);
+                            ? planes_check_pass_spa<Z, CPT, B, false>(smem, radr, D, a.sign_mode)
+                            : planes_check_pass<Z, CPT, B, false>(smem, radr, D, a.sign_mode, ic);
                         if (synd != 0ull) flags[par] = 1;
                     }
                     if (it == 2) TRACE(4);
@@ -506,13 +507,13 @@ planes_role(unsigned char *smem, const RegTables &tb, const DecodeArgs &a)
     flush_outputs();
 }
 
-template <int Z, int CPT, bool HOLES, bool SPA>
+template <int Z, int CPT, bool SPA>
 __global__ void __launch_bounds__(1024)
 qc_planes_kernel(const RegTables tb, const DecodeArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (__builtin_amdgcn_readfirstlane(threadIdx.x / PlanesGeom<Z, CPT>::ZP) == 0)
-        planes_role<Z, CPT, HOLES, 0, SPA>(smem, tb, a);
+        planes_role<Z, CPT, 0, SPA>(smem, tb, a);
     else
-        planes_role<Z, CPT, HOLES, 1, SPA>(smem, tb, a);
+        planes_role<Z, CPT, 1, SPA>(smem, tb, a);
 }

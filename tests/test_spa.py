@@ -150,7 +150,7 @@ def test_gpu_spa_edge_list_kernel_on_near_earth(oracle_mod, monkeypatch):
     llr = y * np.float32(scale)
     with ldpc_amd.Decoder(qc) as eng:
         fast = eng.decode(llr, 50, prec=32, algo=ldpc_amd.ALGO_SUMPRODUCT)
-        assert eng.launch_info(algo=ldpc_amd.ALGO_SUMPRODUCT, prec=32)['lds_bytes'] == 163792
+        assert eng.launch_info(algo=ldpc_amd.ALGO_SUMPRODUCT, prec=32)['lds_bytes'] == 163824
         monkeypatch.setenv('LDPC_HIP_SPA_EDGE_LIST', '1')
         slow = eng.decode(llr, 50, prec=32, algo=ldpc_amd.ALGO_SUMPRODUCT)
         assert eng.launch_info(algo=ldpc_amd.ALGO_SUMPRODUCT, prec=32)['lds_bytes'] == 163520
