@@ -19,7 +19,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-K_INFO = 7154          # message size the metric is quoted on (ldpc.py:486, BASELINE.json)
+K_INFO = 7154          # message size the metric is quoted on (ldpc.py:486)
 N_CODE = 8176
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (spec)
 # algorithmic HBM bytes per frame of the decode kernel: LLR in (8176 x 4) + packed hard

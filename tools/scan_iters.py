@@ -22,7 +22,9 @@ def main():
     import ldpc_amd
     from ldpc_amd import codes
     qc = {'nearEarth': codes.near_earth, 'wifi': codes.wifi_1944_r56,
-          'zero13': lambda: codes.near_earth_zeroed(1, 3)}[args.code]()
+          'zero13': lambda: codes.near_earth_zeroed(1, 3),
+          'w3': lambda: codes.near_earth().with_block(0, 5, [7, 100, 333]),
+          'w1': lambda: codes.near_earth().with_block(1, 9, [42])}[args.code]()
     eng = ldpc_amd.Decoder(qc)
     dev = torch.device('cuda:0')
     stream = torch.cuda.current_stream()
