@@ -42,7 +42,7 @@ __device__ __forceinline__ void lds_put_u32(unsigned char *smem, uint32_t addr, 
 // Channel values of one frame for this thread's CPT columns.  `frame_base` is uniform (scalar
 // registers) and the per-lane part is a 32-bit element offset, laundered so that it is
 // recomputed at each use instead of being kept (as CPT 64-bit addresses) across the decode loop.
-template <int CPT>
+template <int CPT, int Q0 = 0, int Q1 = CPT>
 __device__ __forceinline__ void
 planes_load_frame(const void *llr, int is_f64, int64_t frame_base, uint32_t first, uint32_t stride, float (&out)[CPT])
 {
@@ -50,11 +50,11 @@ planes_load_frame(const void *llr, int is_f64, int64_t frame_base, uint32_t firs
     if (is_f64) {
         const double *p = reinterpret_cast<const double *>(llr) + frame_base;
 #pragma unroll
-        for (int q = 0; q < CPT; ++q) out[q] = (float)p[first + (uint32_t)q * stride];
+        for (int q = Q0; q < Q1; ++q) out[q] = (float)p[first + (uint32_t)q * stride];
     } else {
         const float *p = reinterpret_cast<const float *>(llr) + frame_base;
 #pragma unroll
-        for (int q = 0; q < CPT; ++q) out[q] = p[first + (uint32_t)q * stride];
+        for (int q = Q0; q < Q1; ++q) out[q] = p[first + (uint32_t)q * stride];
     }
 }
 
@@ -393,13 +393,15 @@ planes_role(unsigned char *smem, const RegTables &tb, const DecodeArgs &a)
         }
     };
 
-    for (int64_t frame = blockIdx.x; frame < n_frames; frame += gridDim.x) {
 #ifdef LDPC_TRACE
-        unsigned long long tr[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // phase timing without perturbing the steady state: clock samples are summed in
+    // (scalar) registers and written once when the workgroup has finished
+    unsigned long long tr[11] = {0}, tr_acc[12] = {0}, tr_last = 0;
 #define TRACE(k) tr[k] = clock64()
 #else
 #define TRACE(k)
 #endif
+    for (int64_t frame = blockIdx.x; frame < n_frames; frame += gridDim.x) {
         TRACE(0);
 #pragma unroll
         for (int q = 0; q < CPT; ++q)
@@ -412,6 +414,7 @@ planes_role(unsigned char *smem, const RegTables &tb, const DecodeArgs &a)
         if (live && frame + gridDim.x < n_frames)
             planes_load_frame<CPT>(a.llr, a.llr_f64, (frame + gridDim.x) * N, (uint32_t)(g * Z + ic), MB * Z, ynext);
         flush_outputs();
+        TRACE(3);
 
         // ---- iteration 0 is peeled: its check pass has no previous messages to read
         {
@@ -421,8 +424,10 @@ planes_role(unsigned char *smem, const RegTables &tb, const DecodeArgs &a)
                     : planes_check_pass<Z, CPT, B, true>(smem, radr, D, a.sign_mode, ic);
                 if (synd != 0ull) flags[0] = 1;
             }
-                lds_barrier();
-                const int bad = __builtin_amdgcn_readfirstlane(flags[0]);
+            TRACE(4);
+            lds_barrier();
+            TRACE(5);
+            const int bad = __builtin_amdgcn_readfirstlane(flags[0]);
             if (bad == 0 || a.max_iters <= 0) {
                 my_conv = (bad == 0);
             } else {
@@ -431,16 +436,13 @@ planes_role(unsigned char *smem, const RegTables &tb, const DecodeArgs &a)
                 lds_barrier();
                 for (int it = 1;; ++it) {
                     const int par = it & 1;
-                    if (it == 2) TRACE(3);
                     if (live) {
                         const unsigned long long synd = SPA
                             ? planes_check_pass_spa<Z, CPT, B, false>(smem, radr, D, a.sign_mode)
                             : planes_check_pass<Z, CPT, B, false>(smem, radr, D, a.sign_mode, ic);
                         if (synd != 0ull) flags[par] = 1;
                     }
-                    if (it == 2) TRACE(4);
                     lds_barrier();
-                    if (it == 2) TRACE(5);
                     const int bad2 = __builtin_amdgcn_readfirstlane(flags[par]);   // stop test, ldpc.py:332-335
                     if (bad2 == 0 || it >= a.max_iters) {
                         my_iters = it;
@@ -449,15 +451,13 @@ planes_role(unsigned char *smem, const RegTables &tb, const DecodeArgs &a)
                     }
                     if (tid == 0) flags[par ^ 1] = 0;
                     if (live) variable_pass(y);
-                    if (it == 2) TRACE(6);
                     lds_barrier();
-                    if (it == 2) TRACE(7);
                 }
             }
         }
 
         // ---- hard decisions: 64 consecutive columns per wave and step; lane t keeps step t
-        TRACE(8);
+        TRACE(6);
         unsigned long long mine = 0;
         {
             enum { STEPS = (N + NT - 1) / NT };
@@ -486,25 +486,36 @@ planes_role(unsigned char *smem, const RegTables &tb, const DecodeArgs &a)
             }
 #endif
         }
+        TRACE(7);
 #pragma unroll
         for (int q = 0; q < CPT; ++q) y[q] = ynext[q] * a.llr_scale + 0.0f;
 #ifdef LDPC_TRACE
         asm volatile("" : "+v"(y[0]), "+v"(y[7]));
 #endif
+        TRACE(8);
         lds_barrier();
+        TRACE(9);
         out_bits = mine;
         out_frame = frame;
         out_iters = my_iters;
         out_conv = my_conv;
         out_ones = __builtin_amdgcn_readfirstlane(flags[2]);
+        TRACE(10);
 #ifdef LDPC_TRACE
-        TRACE(9);
-        if (lane == 0 && a.soft)
-            for (int k = 0; k < 10; ++k)
-                reinterpret_cast<unsigned long long *>(a.soft)[(frame * 16 + (tid >> 6)) * 16 + k] = tr[k];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) tr_acc[k] += tr[k + 1] - tr[k];
+        if (tr_last) tr_acc[10] += tr[0] - tr_last;
+        tr_last = tr[10];
+        tr_acc[11] += 1;
 #endif
     }
     flush_outputs();
+#ifdef LDPC_TRACE
+    // phase sums of this wave over all its frames -> [workgroup][wave][12] in the soft-output buffer
+    if (lane == 0 && a.soft)
+        for (int k = 0; k < 12; ++k)
+            reinterpret_cast<unsigned long long *>(a.soft)[((size_t)blockIdx.x * 16 + (tid >> 6)) * 12 + k] = tr_acc[k];
+#endif
 }
 
 template <int Z, int CPT, bool SPA>
