@@ -116,7 +116,10 @@ template <typename T, int MB, int W, int CPT, int FPW, bool HOLES>
 __global__ void __launch_bounds__(1024)
 qc_regular_kernel(const RegTables tb, const DecodeArgs a)
 {
-    enum { NB = CPT * MB, NS = NB * W, SB = RegState<T>::BYTES, NC = CPT * MB * W, CH = 16 };
+    // chunk of the check pass / columns per batch of the variable pass: halved for double,
+    // whose values take two registers each (the larger batches spill)
+    enum { NB = CPT * MB, NS = NB * W, SB = RegState<T>::BYTES, NC = CPT * MB * W,
+           CH = sizeof(T) == 8 ? 8 : 16, VQ = sizeof(T) == 8 ? 1 : 2 };
     static_assert(NS <= 32, "sign bits of a row must fit one register");
     static_assert(NS % 2 == 0 && NC % 2 == 0, "addresses are packed in pairs");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -200,24 +203,35 @@ qc_regular_kernel(const RegTables tb, const DecodeArgs a)
     }
 
     const int64_t n_fblocks = (a.n_frames + FPW - 1) / FPW;
-    // channel values of the first frame; later frames are prefetched during the decode before
-    T ynext[CPT];
+    // float32 channel values are prefetched one frame ahead (8 registers); float64 inputs are
+    // fetched when the frame starts: a second set of doubles would not fit the register budget
+    float ypf[CPT];
+#pragma unroll
+    for (int q = 0; q < CPT; ++q) ypf[q] = 0.0f;
     {
         const int64_t frame0 = (int64_t)blockIdx.x * FPW + f;
+        if (!a.llr_f64 && live && blockIdx.x < n_fblocks && frame0 < a.n_frames) {
+            const float *src = reinterpret_cast<const float *>(a.llr) + frame0 * n + g * Z + i;
 #pragma unroll
-        for (int q = 0; q < CPT; ++q) ynext[q] = T(0);
-        if (live && blockIdx.x < n_fblocks && frame0 < a.n_frames)
-            load_llr_strided<T, CPT>(a.llr, a.llr_f64, frame0 * n + g * Z + i, MB * Z, ynext);
+            for (int q = 0; q < CPT; ++q) ypf[q] = src[(int64_t)q * (MB * Z)];
+        }
     }
     for (int64_t fb = blockIdx.x; fb < n_fblocks; fb += gridDim.x) {
         const int64_t frame = fb * FPW + f;
         const bool valid = frame < a.n_frames;
         T y[CPT];
 #pragma unroll
+        for (int q = 0; q < CPT; ++q) y[q] = T(ypf[q]);
+        if (a.llr_f64 && live && valid) {
+            const double *src = reinterpret_cast<const double *>(a.llr) + frame * n + g * Z + i;
+#pragma unroll
+            for (int q = 0; q < CPT; ++q) y[q] = T(src[(int64_t)q * (MB * Z)]);
+        }
+#pragma unroll
         for (int q = 0; q < CPT; ++q) {
             // "+ 0": a -0.0 input becomes +0.0, which no comparison or sum below can tell
             // apart, and which keeps "sign bit set" equivalent to "< 0" for every message
-            y[q] = ynext[q] * T(a.llr_scale) + T(0);
+            y[q] = y[q] * T(a.llr_scale) + T(0);
             if (live && valid)
                 *reinterpret_cast<T *>(smem + ypost[0] + (uint32_t)q * col_stride) = y[q];
         }
@@ -235,8 +249,11 @@ qc_regular_kernel(const RegTables tb, const DecodeArgs a)
         {
             const int64_t fbn = fb + gridDim.x;
             const int64_t framen = fbn * FPW + f;
-            if (live && fbn < n_fblocks && framen < a.n_frames)
-                load_llr_strided<T, CPT>(a.llr, a.llr_f64, framen * n + g * Z + i, MB * Z, ynext);
+            if (!a.llr_f64 && live && fbn < n_fblocks && framen < a.n_frames) {
+                const float *src = reinterpret_cast<const float *>(a.llr) + framen * n + g * Z + i;
+#pragma unroll
+                for (int q = 0; q < CPT; ++q) ypf[q] = src[(int64_t)q * (MB * Z)];
+            }
         }
 
         for (int it = 0;; ++it) {
@@ -252,7 +269,7 @@ qc_regular_kernel(const RegTables tb, const DecodeArgs a)
                 for (int c0 = 0; c0 < NS; c0 += CH) {
                     T p[CH];
                     // waves that are behind get issue priority, so that a SIMD's waves finish together
-                    set_wave_prio(3 - 2 * (c0 / CH));
+                    set_wave_prio(c0 * 4 / NS >= 3 ? 0 : 3 - c0 * 4 / NS);
 #pragma unroll
                     for (int u = 0; u < CH; ++u) {
                         const int s = c0 + u;
@@ -311,11 +328,11 @@ qc_regular_kernel(const RegTables tb, const DecodeArgs a)
             // ================= variable pass (ldpc.py:295-311, 321-323)
             if (((act_mask >> f) & 1u) && live) {
 #pragma unroll
-                for (int q0 = 0; q0 < CPT; q0 += 2) {
+                for (int q0 = 0; q0 < CPT; q0 += VQ) {
                     set_wave_prio(3 - q0 * 3 / (CPT > 2 ? CPT - 2 : 1));
-                    StateRaw<T> st[2][MB][W];
+                    StateRaw<T> st[VQ][MB][W];
 #pragma unroll
-                    for (int dq = 0; dq < 2; ++dq)
+                    for (int dq = 0; dq < VQ; ++dq)
 #pragma unroll
                         for (int b = 0; b < MB; ++b)
 #pragma unroll
@@ -328,7 +345,7 @@ qc_regular_kernel(const RegTables tb, const DecodeArgs a)
                                 }
                             }
 #pragma unroll
-                    for (int dq = 0; dq < 2; ++dq) {
+                    for (int dq = 0; dq < VQ; ++dq) {
                         const int q = q0 + dq;
                         if (q < CPT) {
                             const int j = g + q * MB;
