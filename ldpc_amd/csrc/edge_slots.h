@@ -1,0 +1,246 @@
+// float32 min-sum for SHORT codes given as an edge list (802.11n n = 1944, toy codes ...):
+// several frames per workgroup, every check-to-variable message explicit in LDS.
+// Included by ldpc_hip.hip.
+//
+// Works for any parity-check matrix with column degree <= 4, row degree <= DC and at most
+// 1024 rows per workgroup (frames per workgroup F = as many as threads and LDS allow).
+//   thread t  -> check row  t mod m  of frame  t / m  of the workgroup's block of F frames
+//               (its edge addresses live in registers for the whole launch), and
+//            -> columns t, t + NT, t + 2 NT, ... of the F*n columns of the block.
+//   LDS       -> one 20-byte record per column { posterior, message slot 0..3 }, slot k holding
+//               the message of the column's k-th check in ascending check index, so the variable
+//               update is the plain ordered sum of ldpc.py:298-303 (unused slots stay +0);
+//               a plane of channel values; per-frame stop flags and counters; one dummy record.
+// Rows shorter than DC point their spare edges at the dummy record (posterior +inf: never a
+// minimum, sign +, hard decision 1 -- the parity of the spare count is folded into the syndrome).
+// Arithmetic and order are those of the other min-sum kernels (ldpc.py:150-163, 174-202,
+// 295-324, 326-337): results are bit-identical.
+#pragma once
+
+struct SlotTables {
+    int m, n, E;
+    int F;                     // frames per workgroup
+    const int32_t *row_ptr;    // [m+1]
+    const int32_t *col_idx;    // [E] ascending inside a row
+    const int32_t *edge_slot;  // [E] rank of the edge's row among the rows of its column
+};
+
+struct SlotGeom {
+    enum { CB = 20, YMAX = 8 };
+    uint32_t y_off, flag_off, cont_off, ones_off, dummy_off, bytes;
+    __host__ __device__ SlotGeom(int n, int F)
+    {
+        const uint32_t cols = (uint32_t)n * (uint32_t)F;
+        y_off = cols * CB;
+        flag_off = y_off + cols * 4;          // [2][F] "syndrome of frame non-zero"
+        cont_off = flag_off + 2u * F * 4;     // [2]    "some frame goes on"
+        ones_off = cont_off + 8;              // [F]
+        dummy_off = ones_off + (uint32_t)F * 4;
+        bytes = (dummy_off + CB + 15) / 16 * 16;
+    }
+};
+
+template <int DC>
+__global__ void __launch_bounds__(1024)
+slot_minsum_kernel(const SlotTables tb, const DecodeArgs a)
+{
+    enum { CB = SlotGeom::CB, YMAX = SlotGeom::YMAX, CH = 4, NCH = DC / CH };
+    static_assert(DC % CH == 0 && DC <= 32, "row degree bound");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int m = tb.m, n = tb.n, F = tb.F;
+    const SlotGeom G(n, F);
+    const int NT = blockDim.x;
+    const int tid = threadIdx.x;
+    const int cols = F * n;
+    const int nbytes = (n + 7) >> 3;
+    int *flags = reinterpret_cast<int *>(smem + G.flag_off);
+    int *cont = reinterpret_cast<int *>(smem + G.cont_off);
+    int *ones_cnt = reinterpret_cast<int *>(smem + G.ones_off);
+    const float INF = __uint_as_float(0x7f800000u);
+
+    // ---- per-launch set-up: my row, the LDS addresses of its edges
+    const bool row_valid = tid < F * m;
+    const int f = row_valid ? tid / m : 0;
+    const int r = row_valid ? tid - f * m : 0;
+    const int e0 = row_valid ? tb.row_ptr[r] : 0;
+    const int deg = row_valid ? tb.row_ptr[r + 1] - e0 : 0;
+    uint32_t radr[DC], madr[DC];
+#pragma unroll
+    for (int e = 0; e < DC; ++e) {
+        uint32_t pa = G.dummy_off, ma = G.dummy_off + 4;
+        if (e < deg) {
+            pa = (uint32_t)(f * n + tb.col_idx[e0 + e]) * CB;
+            ma = pa + 4u + 4u * (uint32_t)tb.edge_slot[e0 + e];
+        }
+        radr[e] = opaque(pa);
+        madr[e] = opaque(ma);
+    }
+    const unsigned long long spare_odd = __ballot(((DC - deg) & 1) != 0);
+    // frame of each of my columns, one byte per column
+    unsigned long long colf = 0;
+#pragma unroll
+    for (int k = 0; k < YMAX; ++k) {
+        const int cg = k * NT + tid;
+        if (cg < cols) colf |= (unsigned long long)(cg / n) << (8 * k);
+    }
+    if (tid < 5) lds_put_u32(smem, G.dummy_off + 4u * tid, tid == 0 ? 0x7f800000u : 0u);
+
+    const int64_t n_fblocks = (a.n_frames + F - 1) / F;
+    // channel values of my columns, prefetched one block of frames ahead (float32 inputs)
+    float ypf[YMAX];
+#pragma unroll
+    for (int k = 0; k < YMAX; ++k) ypf[k] = 0.0f;
+    auto fetch = [&](int64_t fb, float (&dst)[YMAX]) {
+        const int64_t base = fb * F * (int64_t)n;
+        const int64_t total = a.n_frames * (int64_t)n;
+#pragma unroll
+        for (int k = 0; k < YMAX; ++k) {
+            const int cg = k * NT + tid;
+            if (cg < cols && base + cg < total)
+                dst[k] = a.llr_f64 ? (float)reinterpret_cast<const double *>(a.llr)[base + cg]
+                                   : reinterpret_cast<const float *>(a.llr)[base + cg];
+        }
+    };
+    if ((int64_t)blockIdx.x < n_fblocks && !a.llr_f64) fetch(blockIdx.x, ypf);
+
+    for (int64_t fb = blockIdx.x; fb < n_fblocks; fb += gridDim.x) {
+        if (a.llr_f64) fetch(fb, ypf);
+        const int64_t my_frame = fb * F + f;
+        bool my_act = row_valid && my_frame < a.n_frames;
+        // ---- load the block: posterior = channel value, messages = +0 (fresh decoder, ldpc.py:121)
+#pragma unroll
+        for (int k = 0; k < YMAX; ++k) {
+            const int cg = k * NT + tid;
+            if (cg < cols) {
+                const float yv = ypf[k] * a.llr_scale + 0.0f;      // "+ 0": -0.0 -> +0.0
+                const uint32_t rec = (uint32_t)cg * CB;
+                lds_put_f32(smem, rec, yv);
+#pragma unroll
+                for (int s = 1; s <= 4; ++s) lds_put_f32(smem, rec + 4u * s, 0.0f);
+                lds_put_f32(smem, G.y_off + 4u * (uint32_t)cg, yv);
+            }
+        }
+        if (tid < 2 * F) flags[tid] = 0;
+        if (tid < 2) cont[tid] = 0;
+        if (tid < F) ones_cnt[tid] = 0;
+        int my_iters = 0, my_conv = 0;
+        lds_barrier();
+        if (fb + gridDim.x < n_fblocks && !a.llr_f64) fetch(fb + gridDim.x, ypf);
+
+        for (int it = 0;; ++it) {
+            const int par = it & 1;
+            // ================= check pass (+ syndrome of the current posterior)
+            if (my_act) {
+                float min1 = INF, min2 = INF;
+                uint32_t idx = 0, R = 0;
+                unsigned long long synd = spare_odd;
+                float p[2][CH], c[2][CH];
+#pragma unroll
+                for (int k = -1; k < NCH; ++k) {
+                    if (k + 1 < NCH) {
+                        const int nb = (k + 1) & 1;
+#pragma unroll
+                        for (int u = 0; u < CH; ++u) {
+                            p[nb][u] = lds_f32(smem, radr[(k + 1) * CH + u]);
+                            c[nb][u] = lds_f32(smem, madr[(k + 1) * CH + u]);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (k < 0) continue;
+                    if (NCH >= 4 && k % (NCH / 4) == 0) set_wave_prio(3 - k / (NCH / 4) > 0 ? 3 - k / (NCH / 4) : 0);
+                    const int cb = k & 1;
+#pragma unroll
+                    for (int u = 0; u < CH; ++u) {
+                        const int s = k * CH + u;
+                        synd ^= __ballot(p[cb][u] > 0.0f);                          // slicer, ldpc.py:47
+                        const float v = p[cb][u] - c[cb][u];                        // receive, ldpc.py:161
+                        R = __builtin_amdgcn_alignbit(R, __float_as_uint(v), 31);   // (R << 1) | sign(v), ldpc.py:139
+                        const float av = fabsf(v);                                  // ldpc.py:178
+                        const bool lt = av < min1;
+                        min2 = __builtin_amdgcn_fmed3f(min1, min2, av);
+                        idx = lt ? (uint32_t)s : idx;
+                        min1 = __builtin_amdgcn_fmed3f(min1, av, -INF);
+                    }
+                    asm volatile("" : "+v"(min1), "+v"(min2), "+v"(idx), "+v"(R), "+s"(synd));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (DC < 32) R <<= (32 - DC);
+                uint32_t S = __popc(R) & 1u;                                        // spare edges are positive
+                if (a.sign_mode == LDPC_SIGN_CORRECTED) S ^= (uint32_t)deg & 1u;
+                const uint32_t T = R ^ (S ? (0xffffffffu << (32 - DC)) : 0u);
+                const uint32_t m1 = __float_as_uint(min1), m2 = __float_as_uint(min2);
+                set_wave_prio(0);
+#pragma unroll
+                for (int s = 0; s < DC; ++s) {
+                    const uint32_t mag = idx == (uint32_t)s ? m2 : m1;              // ldpc.py:190-191
+                    lds_put_u32(smem, madr[s], mag | ((T << s) & 0x80000000u));
+                    if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                }
+                if ((synd >> (tid & 63)) & 1ull) {
+                    flags[par * F + f] = 1;
+                    cont[par] = 1;
+                }
+            }
+            lds_barrier();
+            // ================= stop test (ldpc.py:332-335): my frame, and whether any frame goes on
+            const int my_bad = flags[par * F + f];
+            const int any_bad = __builtin_amdgcn_readfirstlane(cont[par]);
+            if (my_act && my_bad == 0) {
+                my_iters = it;
+                my_conv = 1;
+                my_act = false;
+            }
+            if (any_bad == 0 || it >= a.max_iters) {
+                if (my_act) { my_iters = it; my_conv = 0; }
+                break;
+            }
+            if (tid < F) flags[(par ^ 1) * F + tid] = 0;
+            if (tid == 0) cont[par ^ 1] = 0;
+            // ================= variable pass of the frames that go on (ldpc.py:295-311, 321-323)
+            set_wave_prio(3);
+#pragma unroll
+            for (int k = 0; k < YMAX; ++k) {
+                const int cg = k * NT + tid;
+                if (cg < cols) {
+                    const int ff = (int)((colf >> (8 * k)) & 0xffull);
+                    if (flags[par * F + ff] != 0) {
+                        const uint32_t rec = (uint32_t)cg * CB;
+                        float acc = lds_f32(smem, rec + 4) + lds_f32(smem, rec + 8);   // 0 + x + y == x + y
+                        acc = acc + lds_f32(smem, rec + 12);
+                        acc = acc + lds_f32(smem, rec + 16);
+                        lds_put_f32(smem, rec, acc + lds_f32(smem, G.y_off + 4u * (uint32_t)cg));   // channel last, ldpc.py:322
+                    }
+                }
+            }
+            set_wave_prio(0);
+            lds_barrier();
+        }
+
+        // ================= outputs
+        for (int x = tid; x < F * nbytes; x += NT) {
+            const int ff = x / nbytes;
+            const int qb = x - ff * nbytes;
+            const int64_t fr = fb * F + ff;
+            if (fr < a.n_frames) {
+                uint32_t byte = 0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (qb * 8 + k < n) byte |= (uint32_t)(lds_f32(smem, (uint32_t)(ff * n + qb * 8 + k) * CB) > 0.0f) << k;
+                if (a.hard) a.hard[fr * nbytes + qb] = (uint8_t)byte;
+                if (byte) atomicAdd(&ones_cnt[ff], (int)__popc(byte));
+            }
+        }
+        if (a.soft) {
+            const int64_t base = fb * F * (int64_t)n, total = a.n_frames * (int64_t)n;
+            for (int cg = tid; cg < cols; cg += NT)
+                if (base + cg < total) reinterpret_cast<float *>(a.soft)[base + cg] = lds_f32(smem, (uint32_t)cg * CB);
+        }
+        lds_barrier();
+        if (row_valid && r == 0 && my_frame < a.n_frames) {
+            if (a.iters) a.iters[my_frame] = my_iters;
+            if (a.conv) a.conv[my_frame] = (uint8_t)my_conv;
+            if (a.ones) a.ones[my_frame] = ones_cnt[f];
+        }
+        lds_barrier();
+    }
+}

@@ -402,6 +402,7 @@ qc_minsum_kernel(const QcTables tb, const DecodeArgs a)
 
 #include "qc_regular.h"
 #include "qc_planes.h"
+#include "edge_slots.h"
 
 // ---------------------------------------------------------------- CSR min-sum kernel
 //
@@ -784,6 +785,8 @@ struct ldpc_handle {
     RegTables reg{};
     // CSR
     CsrTables csr{};
+    const int32_t *edge_slot = nullptr;   // [E] rank of each edge's row inside its column
+    int max_col_deg = 0, min_row_deg = 0;
     std::vector<void *> tables;   // device allocations owned by the handle
     // staging for the host entry points
     DevBuf b_llr, b_hard, b_iters, b_conv, b_ones, b_soft, b_sig, b_unc, b_cnt, b_pf, b_ws;
@@ -797,6 +800,7 @@ struct Launch {
     size_t lds = 0;
     bool spa_lds = false;     // sum-product: posteriors and messages in LDS (else in the workspace)
     bool spa_planes = false;  // sum-product on the message-plane kernel
+    bool slots = false;       // short-code kernel on the edge list (edge_slots.h)
 };
 
 // posteriors [n] + one message per edge, of the arithmetic type
@@ -863,15 +867,21 @@ static int build_csr(ldpc_handle *h, const std::vector<int32_t> &rp, const std::
     std::vector<int32_t> cp(n + 1, 0), crow(E), ce(E);
     for (int e = 0; e < E; ++e) cp[ci[e] + 1]++;
     for (int c = 0; c < n; ++c) cp[c + 1] += cp[c];
-    std::vector<int32_t> fill(cp.begin(), cp.end() - 1);
+    std::vector<int32_t> fill(cp.begin(), cp.end() - 1), eslot(E);
     for (int r = 0; r < m; ++r)
         for (int e = rp[r]; e < rp[r + 1]; ++e) {
             const int pos = fill[ci[e]]++;
             crow[pos] = r;
             ce[pos] = e - rp[r];
+            eslot[e] = pos - cp[ci[e]];
         }
     h->csr.m = m; h->csr.n = n; h->csr.E = E;
+    h->max_col_deg = 0;
+    for (int c = 0; c < n; ++c) h->max_col_deg = std::max(h->max_col_deg, cp[c + 1] - cp[c]);
+    h->min_row_deg = m > 0 ? rp[1] - rp[0] : 0;
+    for (int r = 0; r < m; ++r) h->min_row_deg = std::min(h->min_row_deg, rp[r + 1] - rp[r]);
     int rc;
+    if ((rc = upload(h, eslot, &h->edge_slot))) return rc;
     if ((rc = upload(h, rp, &h->csr.row_ptr)) || (rc = upload(h, ci, &h->csr.col_idx)) ||
         (rc = upload(h, cp, &h->csr.col_ptr)) || (rc = upload(h, crow, &h->csr.col_row)) ||
         (rc = upload(h, ce, &h->csr.col_e)))
@@ -1148,6 +1158,41 @@ static size_t csr_ws_stride(const ldpc_handle *h, int prec)
     return (b + 255) & ~(size_t)255;
 }
 
+// Short codes, float32: several frames per workgroup with explicit messages (edge_slots.h).
+static int slots_frames(const ldpc_handle *h)
+{
+    if (h->m <= 0 || h->m > 1024) return 0;
+    int F = std::min(1024 / h->m, 32);
+    while (F > 0 && SlotGeom(h->n, F).bytes > h->lds_max) --F;
+    return F;
+}
+
+static bool slots_applies(const ldpc_handle *h, int prec, bool chained)
+{
+    const char *off = getenv("LDPC_HIP_NO_SLOTS");
+    if (prec != 32 || chained || (off && off[0] == '1')) return false;
+    if (h->max_col_deg > 4 || h->max_row_deg > 24 || h->min_row_deg < 2) return false;
+    const int F = slots_frames(h);
+    if (F < 1) return false;
+    const int nt = (F * h->m + 63) / 64 * 64;
+    return (long long)F * h->n <= (long long)SlotGeom::YMAX * nt;
+}
+
+static int slots_pick(const ldpc_handle *h, Launch *L)
+{
+    const int d = h->max_row_deg;
+    L->fn = d <= 8    ? reinterpret_cast<const void *>(&slot_minsum_kernel<8>)
+            : d <= 12 ? reinterpret_cast<const void *>(&slot_minsum_kernel<12>)
+            : d <= 16 ? reinterpret_cast<const void *>(&slot_minsum_kernel<16>)
+            : d <= 20 ? reinterpret_cast<const void *>(&slot_minsum_kernel<20>)
+                      : reinterpret_cast<const void *>(&slot_minsum_kernel<24>);
+    L->fpw = slots_frames(h);
+    L->block = (L->fpw * h->m + 63) / 64 * 64;
+    L->lds = SlotGeom(h->n, L->fpw).bytes;
+    L->slots = true;
+    return 0;
+}
+
 static int select_launch(ldpc_handle *h, int algo, int prec, int64_t n_frames, bool chained, Launch *L)
 {
     if (algo != LDPC_ALGO_MINSUM && algo != LDPC_ALGO_SUMPRODUCT)
@@ -1179,6 +1224,17 @@ static int select_launch(ldpc_handle *h, int algo, int prec, int64_t n_frames, b
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, L->fn, L->block, L->lds));
         if (per_cu < 1) per_cu = 1;
         L->grid = (int)std::max<int64_t>(1, std::min<int64_t>(n_frames, (int64_t)h->n_cu * per_cu));
+        return 0;
+    }
+    if (!(h->is_qc && planes_applies(h, prec, chained)) && slots_applies(h, prec, chained)) {
+        int rc = slots_pick(h, L);
+        if (rc) return rc;
+        HIP_TRY(hipFuncSetAttribute(L->fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L->lds));
+        int per_cu = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, L->fn, L->block, L->lds));
+        if (per_cu < 1) per_cu = 1;
+        const int64_t fblocks = (n_frames + L->fpw - 1) / L->fpw;
+        L->grid = (int)std::max<int64_t>(1, std::min<int64_t>(fblocks, (int64_t)h->n_cu * per_cu));
         return 0;
     }
     if (h->is_qc) {
@@ -1223,7 +1279,14 @@ static int launch_decode(ldpc_handle *h, int algo, int prec, const DecodeArgs &a
     Launch L;
     int rc = select_launch(h, algo, prec, args.n_frames, args.chain != nullptr, &L);
     if (rc) return rc;
-    if (algo == LDPC_ALGO_SUMPRODUCT && !L.spa_planes) {
+    if (L.slots) {
+        SlotTables tb;
+        tb.m = h->m; tb.n = h->n; tb.E = h->E; tb.F = L.fpw;
+        tb.row_ptr = h->csr.row_ptr; tb.col_idx = h->csr.col_idx; tb.edge_slot = h->edge_slot;
+        DecodeArgs a = args;
+        void *kargs[] = {&tb, &a};
+        HIP_TRY(hipLaunchKernel(L.fn, dim3(L.grid), dim3(L.block), kargs, L.lds, h->stream));
+    } else if (algo == LDPC_ALGO_SUMPRODUCT && !L.spa_planes) {
         size_t stride = (spa_state_bytes(h, prec) + 255) & ~(size_t)255;
         if (!L.spa_lds && (rc = h->b_ws.ensure(stride * (size_t)L.grid))) return rc;
         CsrTables tb = h->csr;

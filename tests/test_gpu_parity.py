@@ -288,3 +288,29 @@ def test_bench_scale_properties(engines):
     torch.cuda.synchronize()
     eng.set_stream(None)
     assert torch.equal(iters2, iters[perm])
+
+
+def test_short_code_kernel_against_the_other_paths(engines, oracle_mod, monkeypatch):
+    """float32 decoding of short codes runs several frames per workgroup on the edge list
+    (802.11n: 3 frames); the older per-block kernels must give the same bits."""
+    for name in ('wifi_5_6', 'rand_24_48'):
+        eng = engines(name)
+        _, H = build_code(name)
+        orc = oracle_mod.Oracle(H)
+        Y = make_llrs(77, 5.0 if name == 'wifi_5_6' else 2.0, H.shape[1], 67)      # ragged: 67 = 22*3 + 1
+        hard, iters, conv, soft = orc.minsum(Y, 30, prec=32, threads=8)
+        info = eng.launch_info(prec=32)
+        assert info['frames_per_wg'] >= 3
+        fast = eng.decode(Y, 30, prec=32, want_soft=True)
+        monkeypatch.setenv('LDPC_HIP_NO_SLOTS', '1')
+        assert eng.launch_info(prec=32) != info
+        slow = eng.decode(Y, 30, prec=32, want_soft=True)
+        monkeypatch.delenv('LDPC_HIP_NO_SLOTS')
+        for r in (fast, slow):
+            assert np.array_equal(r['iters'], iters) and np.array_equal(r['converged'], conv)
+            assert np.array_equal(r['hard'], hard) and np.array_equal(r['soft'], soft)
+            assert np.array_equal(r['ones'], hard.sum(1))
+        # corrected sign rule (odd check degrees decode) through the same kernel
+        h2, i2, c2, _ = orc.minsum(Y, 30, prec=32, sign_mode=1, want_soft=False, threads=8)
+        r2 = eng.decode(Y, 30, prec=32, sign_mode=1)
+        assert np.array_equal(r2['iters'], i2) and np.array_equal(r2['hard'], h2)
