@@ -196,3 +196,53 @@ def observation_to_qc(compressedMatrix):
     blocks = [[sorted(int((-loc) % Z) for loc in np.flatnonzero(top[b][j * Z:(j + 1) * Z]))
                for j in range(16)] for b in range(2)]
     return QCCode(Z, blocks)
+
+
+# ---------------------------------------------------------------------------
+# Systematic quasi-cyclic generators G = [I | B], B made of Z x Z circulants given by the
+# first row of each (hexadecimal, most significant bit first; fileHandler.py:68-135, 144-160).
+def parse_generator_file(path, dim0, Z):
+    """First rows of the circulants of B: uint8 [dim0 // Z][2][Z].  Line 2i holds the left,
+    line 2i+1 the right circulant of block-row i; a line of exactly Z+1 bits loses its
+    leading pad bit (fileHandler.py:126-135, 151-156)."""
+    with open(path) as fid:
+        lines = [ln.strip() for ln in fid.readlines()]
+    rows = []
+    for i in range(dim0 // Z):
+        pair = []
+        for ln in (lines[2 * i], lines[2 * i + 1]):
+            bits = np.unpackbits(np.frombuffer(bytes.fromhex(ln), dtype=np.uint8))
+            if len(bits) < Z:
+                raise ValueError('generator line shorter than the circulant size')
+            pair.append(bits[1:Z + 1].copy() if len(bits) > Z else bits)
+        rows.append(pair)
+    return np.array(rows, dtype=np.uint8)
+
+
+class SystematicQCEncoder:
+    """codeword = [message | message . B mod 2] for G = [I | B] (readMatrixFromFile with
+    isGenerator=True, fileHandler.py:151-160).  Row r = i*Z + t of B is the first row of
+    block-row i's circulants rotated right by t."""
+
+    def __init__(self, first_rows, Z):
+        first_rows = np.asarray(first_rows, dtype=np.uint8)
+        self.Z = int(Z)
+        self.kb, self.pb = first_rows.shape[0], first_rows.shape[1]
+        self.k = self.kb * self.Z
+        self.n = self.k + self.pb * self.Z
+        idx = (np.arange(Z)[None, :] - np.arange(Z)[:, None]) % Z          # [t, col] -> position in the first row
+        B = np.zeros((self.k, self.pb * Z), dtype=np.uint8)
+        for i in range(self.kb):
+            for j in range(self.pb):
+                B[i * Z:(i + 1) * Z, j * Z:(j + 1) * Z] = first_rows[i, j][idx]
+        self.B = B
+
+    def encode(self, messages):
+        msg = np.atleast_2d(np.asarray(messages)).astype(np.uint8)
+        if msg.shape[1] != self.k:
+            raise ValueError(f'message length {msg.shape[1]} != {self.k}')
+        parity = (msg.astype(np.int32) @ self.B.astype(np.int32)) & 1
+        return np.concatenate([msg, parity.astype(np.uint8)], axis=1)
+
+    def to_dense(self, dtype=np.int32):
+        return np.hstack([np.eye(self.k, dtype=dtype), self.B.astype(dtype)])

@@ -1,7 +1,7 @@
 """Code-construction entry points of the reference's ``fileHandler`` that sit on
 the decode path: dense parity-check matrices from hot-position files
-(fileHandler.py:137-181).  Generator matrices (isGenerator=True) are not on
-this path (every evaluation call passes G='None') and are not built here.
+(fileHandler.py:137-181), and systematic generator matrices from hexadecimal
+first-row files (fileHandler.py:68-135, 151-160).
 """
 import numpy as np
 
@@ -21,8 +21,9 @@ def readMatrixFromFile(fileName, dim0, dim1, circulantSize, isRow=True, isHex=Tr
     per circulant, the hot positions of its first row; lines run block-row after
     block-row (fileHandler.py:144-181 with isGenerator=False)."""
     if isGenerator:
-        raise NotImplementedError('generator matrices are not part of the decode path; '
-                                  'call with isGenerator=False for a parity-check matrix')
+        # [I | B], dim0 x (dim0 + 2*circulantSize) (fileHandler.py:151-160)
+        return codes.SystematicQCEncoder(codes.parse_generator_file(fileName, dim0, circulantSize),
+                                         circulantSize).to_dense(GENERAL_CODE_MATRIX_DATA_TYPE)
     return readCodeFromFile(fileName, dim0, dim1, circulantSize).to_dense(GENERAL_CODE_MATRIX_DATA_TYPE)
 
 
