@@ -1,4 +1,4 @@
-// float32 min-sum for SHORT codes given as an edge list (802.11n n = 1944, toy codes ...):
+// float32 min-sum (and sum-product) for SHORT codes given as an edge list (802.11n n = 1944, toy codes ...):
 // several frames per workgroup, every check-to-variable message explicit in LDS.
 // Included by ldpc_hip.hip.
 //
@@ -40,7 +40,9 @@ struct SlotGeom {
     }
 };
 
-template <int DC>
+// SPA = true: sum-product check rule (stated with csr_spa_kernel; phi from planes_phi) in
+// place of min-sum; everything else is shared.
+template <int DC, bool SPA>
 __global__ void __launch_bounds__(1024)
 slot_minsum_kernel(const SlotTables tb, const DecodeArgs a)
 {
@@ -130,7 +132,7 @@ slot_minsum_kernel(const SlotTables tb, const DecodeArgs a)
         for (int it = 0;; ++it) {
             const int par = it & 1;
             // ================= check pass (+ syndrome of the current posterior)
-            if (my_act) {
+            if (my_act && !SPA) {
                 float min1 = INF, min2 = INF;
                 uint32_t idx = 0, R = 0;
                 unsigned long long synd = spare_odd;
@@ -175,6 +177,47 @@ slot_minsum_kernel(const SlotTables tb, const DecodeArgs a)
                     const uint32_t mag = idx == (uint32_t)s ? m2 : m1;              // ldpc.py:190-191
                     lds_put_u32(smem, madr[s], mag | ((T << s) & 0x80000000u));
                     if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                }
+                if ((synd >> (tid & 63)) & 1ull) {
+                    flags[par * F + f] = 1;
+                    cont[par] = 1;
+                }
+            }
+            if (my_act && SPA) {
+                float F1 = 0.0f, rest = 0.0f;      // every real F is > 0: the first edge displaces the initial 0
+                uint32_t idx = 0, R = 0;
+                unsigned long long synd = spare_odd;
+#pragma unroll
+                for (int s = 0; s < DC; ++s) {
+                    const float pv = lds_f32(smem, radr[s]);
+                    const float v = pv - lds_f32(smem, madr[s]);
+                    synd ^= __ballot(pv > 0.0f);
+                    R = __builtin_amdgcn_alignbit(R, __float_as_uint(v), 31);
+                    const float av = fabsf(v);
+                    float Fe = planes_phi(__builtin_amdgcn_fmed3f(av, 1e-12f, 80.0f));
+                    Fe = av == INF ? 0.0f : Fe;                                     // spare edge: no term
+                    if (s < deg) lds_put_f32(smem, madr[s], Fe);                    // spare edges share one slot: leave it alone
+                    const bool gt = Fe > F1;
+                    rest = rest + (gt ? F1 : Fe);
+                    idx = gt ? (uint32_t)s : idx;
+                    F1 = gt ? Fe : F1;
+                    if ((s & 3) == 3) {
+                        asm volatile("" : "+v"(F1), "+v"(rest), "+v"(idx), "+v"(R));
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                if (DC < 32) R <<= (32 - DC);
+                uint32_t S = __popc(R) & 1u;
+                if (a.sign_mode == LDPC_SIGN_CORRECTED) S ^= (uint32_t)deg & 1u;
+                const uint32_t T = R ^ (S ? (0xffffffffu << (32 - DC)) : 0u);
+#pragma unroll
+                for (int s = 0; s < DC; ++s) {
+                    if (s < deg) {
+                        const float Fe = lds_f32(smem, madr[s]);
+                        const float x = idx == (uint32_t)s ? rest : (rest - Fe) + F1;
+                        const float mag = planes_phi(__builtin_amdgcn_fmed3f(x, 1e-12f, 80.0f));
+                        lds_put_u32(smem, madr[s], __float_as_uint(mag) | ((T << s) & 0x80000000u));
+                    }
                 }
                 if ((synd >> (tid & 63)) & 1ull) {
                     flags[par * F + f] = 1;

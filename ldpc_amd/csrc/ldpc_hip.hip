@@ -1178,14 +1178,19 @@ static bool slots_applies(const ldpc_handle *h, int prec, bool chained)
     return (long long)F * h->n <= (long long)SlotGeom::YMAX * nt;
 }
 
-static int slots_pick(const ldpc_handle *h, Launch *L)
+template <bool SPA>
+static const void *slots_fn(int d)
 {
-    const int d = h->max_row_deg;
-    L->fn = d <= 8    ? reinterpret_cast<const void *>(&slot_minsum_kernel<8>)
-            : d <= 12 ? reinterpret_cast<const void *>(&slot_minsum_kernel<12>)
-            : d <= 16 ? reinterpret_cast<const void *>(&slot_minsum_kernel<16>)
-            : d <= 20 ? reinterpret_cast<const void *>(&slot_minsum_kernel<20>)
-                      : reinterpret_cast<const void *>(&slot_minsum_kernel<24>);
+    return d <= 8    ? reinterpret_cast<const void *>(&slot_minsum_kernel<8, SPA>)
+           : d <= 12 ? reinterpret_cast<const void *>(&slot_minsum_kernel<12, SPA>)
+           : d <= 16 ? reinterpret_cast<const void *>(&slot_minsum_kernel<16, SPA>)
+           : d <= 20 ? reinterpret_cast<const void *>(&slot_minsum_kernel<20, SPA>)
+                     : reinterpret_cast<const void *>(&slot_minsum_kernel<24, SPA>);
+}
+
+static int slots_pick(const ldpc_handle *h, bool spa, Launch *L)
+{
+    L->fn = spa ? slots_fn<true>(h->max_row_deg) : slots_fn<false>(h->max_row_deg);
     L->fpw = slots_frames(h);
     L->block = (L->fpw * h->m + 63) / 64 * 64;
     L->lds = SlotGeom(h->n, L->fpw).bytes;
@@ -1203,7 +1208,20 @@ static int select_launch(ldpc_handle *h, int algo, int prec, int64_t n_frames, b
         if (chained)
             return fail(LDPC_E_UNSUPPORTED, "the re-used-decoder mode exists for min-sum only");
         const char *edge_only = getenv("LDPC_HIP_SPA_EDGE_LIST");
-        if (h->is_qc && planes_applies(h, prec, false) && !(edge_only && edge_only[0] == '1')) {
+        const bool fast_ok = !(edge_only && edge_only[0] == '1');
+        if (fast_ok && !(h->is_qc && planes_applies(h, prec, false)) && slots_applies(h, prec, false)) {
+            // short codes, float32: several frames per workgroup (edge_slots.h)
+            int rc = slots_pick(h, true, L);
+            if (rc) return rc;
+            HIP_TRY(hipFuncSetAttribute(L->fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L->lds));
+            int per_cu = 0;
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, L->fn, L->block, L->lds));
+            if (per_cu < 1) per_cu = 1;
+            const int64_t fblocks = (n_frames + L->fpw - 1) / L->fpw;
+            L->grid = (int)std::max<int64_t>(1, std::min<int64_t>(fblocks, (int64_t)h->n_cu * per_cu));
+            return 0;
+        }
+        if (h->is_qc && planes_applies(h, prec, false) && fast_ok) {
             // float32 NearEarth-shaped codes: message planes in LDS, hardware transcendentals
             int rc = planes_pick(h, true, L);
             if (rc) return rc;
@@ -1227,7 +1245,7 @@ static int select_launch(ldpc_handle *h, int algo, int prec, int64_t n_frames, b
         return 0;
     }
     if (!(h->is_qc && planes_applies(h, prec, chained)) && slots_applies(h, prec, chained)) {
-        int rc = slots_pick(h, L);
+        int rc = slots_pick(h, algo == LDPC_ALGO_SUMPRODUCT, L);
         if (rc) return rc;
         HIP_TRY(hipFuncSetAttribute(L->fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L->lds));
         int per_cu = 0;
