@@ -84,15 +84,23 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    # LDPC_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer cards than ranks
+    # (ranks share cards, counters are reduced through host memory); the default is RCCL.
+    backend = os.environ.get('LDPC_BENCH_BACKEND', 'nccl')
+    n_cards = torch.cuda.device_count()
+    card = local_rank % max(n_cards, 1) if backend != 'nccl' else local_rank
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
-    dev = torch.device('cuda', local_rank)
+        torch.cuda.set_device(card)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', card))
+        else:
+            dist.init_process_group(backend)
+    dev = torch.device('cuda', card)
     torch.cuda.set_device(dev)
 
     F = args.frames
-    eng = ldpc_amd.Decoder(codes.near_earth(), device=local_rank)
+    eng = ldpc_amd.Decoder(codes.near_earth(), device=card)
     stream = torch.cuda.current_stream()
     eng.set_stream(stream.cuda_stream)
     n, nbytes = eng.n, eng.nbytes
@@ -124,7 +132,12 @@ def main():
                          (ones != 0).sum(), ones.sum(dtype=torch.int64), iters.sum(dtype=torch.int64),
                          unc.sum(dtype=torch.int64), (conv == 0).sum()])
         if world > 1:
-            dist.all_reduce(c)          # the path's only exchange: error counters (RCCL)
+            if backend == 'nccl':
+                dist.all_reduce(c)      # the path's only exchange: error counters (RCCL)
+            else:
+                h = c.cpu()
+                dist.all_reduce(h)
+                c = h.to(dev)
         return c
 
     for _ in range(args.warmup):
@@ -148,7 +161,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=dev if backend == 'nccl' else 'cpu', dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kernel_ms = [a.elapsed_time(b) for a, b in ev]
