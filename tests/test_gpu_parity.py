@@ -314,3 +314,60 @@ def test_short_code_kernel_against_the_other_paths(engines, oracle_mod, monkeypa
         h2, i2, c2, _ = orc.minsum(Y, 30, prec=32, sign_mode=1, want_soft=False, threads=8)
         r2 = eng.decode(Y, 30, prec=32, sign_mode=1)
         assert np.array_equal(r2['iters'], i2) and np.array_equal(r2['hard'], h2)
+
+
+def test_full_size_batch_properties(engines):
+    """The benchmark's own batch (10^6 NearEarth frames at 3.5 dB, float32): no oracle run at
+    this size, so size-independent properties -- a checksum of checksums (per-frame ones
+    counts against the packed bits), status vs iteration budget, run-to-run determinism,
+    independence of how the batch is split, and agreement with a float64 decode of a slice
+    through the golden-pinned kernel wherever both converge."""
+    import torch
+    eng = engines('nearEarth')
+    n, F = eng.n, 1_000_000
+    dev = torch.device('cuda:0')
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    llr = torch.empty((F, n), dtype=torch.float32, device=dev)
+    eng.channel_awgn_device(llr, F, 3.5, seed=460101, first_frame=0)
+    out = []
+    for rep in range(2):
+        hard = torch.zeros((F, eng.nbytes), dtype=torch.uint8, device=dev)
+        iters = torch.full((F,), -1, dtype=torch.int32, device=dev)
+        conv = torch.full((F,), 7, dtype=torch.uint8, device=dev)
+        ones = torch.full((F,), -1, dtype=torch.int32, device=dev)
+        eng.decode_device(llr, F, 50, prec=32, d_hard=hard, d_iters=iters, d_conv=conv, d_ones=ones)
+        torch.cuda.synchronize()
+        out.append((hard, iters, conv, ones))
+    (hard, iters, conv, ones), (hard2, iters2, conv2, ones2) = out
+    assert torch.equal(hard, hard2) and torch.equal(iters, iters2) and torch.equal(conv, conv2) and torch.equal(ones, ones2)
+    del hard2, iters2, conv2, ones2, out
+    lut = torch.tensor([bin(v).count('1') for v in range(256)], dtype=torch.int32, device=dev)
+    pop = torch.zeros(F, dtype=torch.int32, device=dev)
+    for f0 in range(0, F, 100000):
+        pop[f0:f0 + 100000] = lut[hard[f0:f0 + 100000].long()].sum(1, dtype=torch.int32)
+    assert torch.equal(pop, ones)                                     # checksum of checksums
+    assert int(((conv != 0) & (conv != 1)).sum()) == 0
+    assert int(((iters < 0) | (iters > 50)).sum()) == 0
+    assert int(((conv == 0) & (iters != 50)).sum()) == 0             # gave up <=> budget spent
+    assert int(((conv == 1) & (ones != 0)).sum()) <= 2                # a converged frame is the sent word (or, rarely, another codeword)
+    fer = float((ones != 0).float().mean())
+    assert 1e-3 < fer < 5e-3 and 6.5 < float(iters.float().mean()) < 7.5
+    # splitting the batch differently changes nothing
+    a, b = 333_333, 777_001
+    it_part = torch.empty(b - a, dtype=torch.int32, device=dev)
+    hd_part = torch.empty((b - a, eng.nbytes), dtype=torch.uint8, device=dev)
+    eng.decode_device(llr[a:b], b - a, 50, prec=32, d_hard=hd_part, d_iters=it_part)
+    torch.cuda.synchronize()
+    assert torch.equal(it_part, iters[a:b]) and torch.equal(hd_part, hard[a:b])
+    # float64 decode (the arithmetic pinned by the reference's golden vectors) of a slice
+    S = 50_000
+    it64 = torch.empty(S, dtype=torch.int32, device=dev)
+    cv64 = torch.empty(S, dtype=torch.uint8, device=dev)
+    hd64 = torch.empty((S, eng.nbytes), dtype=torch.uint8, device=dev)
+    eng.decode_device(llr[:S], S, 50, prec=64, d_hard=hd64, d_iters=it64, d_conv=cv64)
+    torch.cuda.synchronize()
+    eng.set_stream(None)
+    both = (cv64 == 1) & (conv[:S] == 1)
+    assert float(both.float().mean()) > 0.99
+    assert torch.equal(hd64[both], hard[:S][both])
+    assert float((it64[both] == iters[:S][both]).float().mean()) > 0.999   # rounding may move a frame by one iteration
