@@ -137,3 +137,22 @@ def test_device_rng_evaluation_statistics():
     # anchors embedded in the reference (common.py:113-114; rewardInvestigation.ipynb:64):
     # BER ~0.02 at 3.0 dB, dropping to 0 by 3.4-3.6 dB
     assert 0.012 < ber[0] < 0.03 and ber[1] < 0.004 and ber[2] == 0
+
+
+def test_near_earth_quality_anchor_of_the_reference_notebook():
+    """rewardInvestigation.ipynb (cell 3, lines 62-94 of the file) holds the output of
+    ldpcCUDA.testNearEarth(10) -- seed 460101, 3.0/3.2/3.4 dB, 10 frames each, float32:
+    berDecoded [0.02117172 0.01221869 0.], fitted line [-0.05026939 0.17176406], reward
+    0.39563919692811345.  Same seed and noise here; frames that do not converge are chaotic
+    (the reference's kernels add in a different order and test the syndrome every 6th
+    iteration), so their error counts agree statistically, the rest exactly."""
+    from ldpc_amd import codes, ldpcHIP
+    roi = [3.0, 3.2, 3.4]
+    st = ldpcHIP.evaluateCodeCuda(460101, roi, 50, codes.near_earth().to_dense(), 10)
+    scatterSnr, scatterBer, scatterItr, snrAxis, _, berData, _ = st.getStatsV2()
+    assert berData[2] == 0.0                                            # 3.4 dB: every frame decodes
+    assert abs(berData[0] - 0.02117172) < 0.003 and abs(berData[1] - 0.01221869) < 0.003
+    p = np.polyfit(scatterSnr, scatterBer, 1)
+    assert abs(p[0] - (-0.05026939)) < 0.005 and abs(p[1] - 0.17176406) < 0.015
+    integ = (np.poly1d([1]) - np.poly1d(p)).integ()
+    assert abs((integ(roi[-1]) - integ(roi[0])) - 0.39563919692811345) < 3e-4
