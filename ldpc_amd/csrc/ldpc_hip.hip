@@ -783,6 +783,9 @@ struct ldpc_handle {
     bool reg_holes = false;
     int reg_w = 0;
     RegTables reg{};
+    // message-plane kernel (2 x 16 circulants of size 511, every weight <= 2)
+    bool planes_ok = false;
+    PlanesTables planes{};
     // CSR
     CsrTables csr{};
     const int32_t *edge_slot = nullptr;   // [E] rank of each edge's row inside its column
@@ -801,6 +804,7 @@ struct Launch {
     bool spa_lds = false;     // sum-product: posteriors and messages in LDS (else in the workspace)
     bool spa_planes = false;  // sum-product on the message-plane kernel
     bool slots = false;       // short-code kernel on the edge list (edge_slots.h)
+    bool planes = false;      // message-plane kernel (qc_planes.h)
 };
 
 // posteriors [n] + one message per edge, of the arithmetic type
@@ -987,6 +991,24 @@ extern "C" int ldpc_create_qc(int device, int Z, int mb, int nb, const int32_t *
         ldpc_destroy(h);
         return rc;
     }
+    if (mb == 2 && nb == 16 && Z == 511) {
+        bool light = true;
+        for (int k = 0; k < nblk; ++k) light = light && (blk_ptr[k + 1] - blk_ptr[k] <= 2);
+        if (light) {
+            std::vector<int32_t> sh((size_t)mb * nb * 2, 0);
+            for (int b = 0; b < mb; ++b)
+                for (int j = 0; j < nb; ++j) {
+                    std::vector<int32_t> v(shifts + blk_ptr[b * nb + j], shifts + blk_ptr[b * nb + j + 1]);
+                    std::sort(v.begin(), v.end());
+                    for (size_t k = 0; k < v.size(); ++k) {
+                        sh[((size_t)b * nb + j) * 2 + k] = v[k];
+                        h->planes.edge_mask[b] |= 1u << (2 * j + (int)k);
+                    }
+                }
+            if ((rc = upload(h, sh, &h->planes.shifts))) { ldpc_destroy(h); return rc; }
+            h->planes_ok = true;
+        }
+    }
     // the same graph as an edge list, columns ascending inside a row (used by the sum-product kernel)
     {
         std::vector<int32_t> rp((size_t)h->m + 1, 0), ci;
@@ -1127,14 +1149,15 @@ static int reg_pick(const ldpc_handle *h, Launch *L)
 static bool planes_applies(const ldpc_handle *h, int prec, bool chained)
 {
     const char *off = getenv("LDPC_HIP_NO_PLANES");
-    return h->is_regular && prec == 32 && !chained && h->qc.mb == 2 && h->qc.nb == 16 && h->reg_w == 2 &&
-           h->qc.Z == 511 && (size_t)PlanesGeom<511, 8>::LDS_BYTES <= h->lds_max && !(off && off[0] == '1');
+    return h->planes_ok && prec == 32 && !chained &&
+           (size_t)PlanesGeom<511, 8>::LDS_BYTES <= h->lds_max && !(off && off[0] == '1');
 }
 
 static int planes_pick(const ldpc_handle *h, bool spa, Launch *L)
 {
     L->fn = spa ? reinterpret_cast<const void *>(&qc_planes_kernel<511, 8, true>)
                 : reinterpret_cast<const void *>(&qc_planes_kernel<511, 8, false>);
+    L->planes = true;
     L->block = 2 * PlanesGeom<511, 8>::ZP;
     L->fpw = 1;
     L->lds = PlanesGeom<511, 8>::LDS_BYTES;
@@ -1304,7 +1327,12 @@ static int launch_decode(ldpc_handle *h, int algo, int prec, const DecodeArgs &a
         DecodeArgs a = args;
         void *kargs[] = {&tb, &a};
         HIP_TRY(hipLaunchKernel(L.fn, dim3(L.grid), dim3(L.block), kargs, L.lds, h->stream));
-    } else if (algo == LDPC_ALGO_SUMPRODUCT && !L.spa_planes) {
+    } else if (L.planes) {
+        PlanesTables tb = h->planes;
+        DecodeArgs a = args;
+        void *kargs[] = {&tb, &a};
+        HIP_TRY(hipLaunchKernel(L.fn, dim3(L.grid), dim3(L.block), kargs, L.lds, h->stream));
+    } else if (algo == LDPC_ALGO_SUMPRODUCT) {
         size_t stride = (spa_state_bytes(h, prec) + 255) & ~(size_t)255;
         if (!L.spa_lds && (rc = h->b_ws.ensure(stride * (size_t)L.grid))) return rc;
         CsrTables tb = h->csr;

@@ -19,11 +19,12 @@
 // Same arithmetic in the same order as the other kernels (ldpc.py:150-163,
 // 174-202, 295-324): results are bit-identical.
 //
-// Zeroed circulants (the variants of testMatricesGeneratorScript.py:23-34) run the same
-// code: the two edges a row loses point to one dummy record whose posterior is +inf.  Such
-// an edge has |v| = inf (never a minimum), sign + and hard decision 1 -- twice per row, so
-// the parity is untouched; what the row writes back lands in the dummy's message slots.
-// The message slots no check owns any more are zeroed once per launch and add +0.
+// Circulants of weight 0 or 1 (the zeroed variants of testMatricesGeneratorScript.py:23-34,
+// light circulants a gym action installs, ldpc_env.py:206-210) run the same code: an edge a
+// row lacks points to one dummy record whose posterior is +inf.  Such an edge has |v| = inf
+// (never a minimum), sign + and hard decision 1; a row with an odd number of them starts its
+// parity from 1.  What the row writes back lands in the dummy's message slots.  The message
+// slots no check owns are zeroed once per launch and add +0.
 #pragma once
 
 __device__ __forceinline__ float lds_f32(const unsigned char *smem, uint32_t addr)
@@ -65,6 +66,11 @@ planes_load_frame(const void *llr, int is_f64, int64_t frame_base, uint32_t firs
 #define PLANES_VB 4                 // columns per batch of the variable pass
 #endif
 
+struct PlanesTables {
+    uint32_t edge_mask[2];   // [block-row] bit 2j+k set: shift k of circulant (b, j) exists (weight 0, 1 or 2)
+    const int32_t *shifts;   // [2][NB][2] ascending inside a circulant; entries of missing shifts unused
+};
+
 template <int Z, int CPT>
 struct PlanesGeom {
     enum { MB = 2, W = 2, NB = CPT * MB, NS = NB * W, N = NB * Z, ZP = (Z + 63) / 64 * 64,
@@ -80,14 +86,15 @@ struct PlanesGeom {
 // whose parity check on the current hard decisions fails.
 template <int Z, int CPT, int B, bool FIRST>
 __device__ __forceinline__ unsigned long long
-planes_check_pass(unsigned char *smem, const uint32_t (&radr)[CPT * 4], int D, int sign_mode, int ic)
+planes_check_pass(unsigned char *smem, const uint32_t (&radr)[CPT * 4], int D, int sign_mode, int ic,
+                  unsigned long long synd0)
 {
     typedef PlanesGeom<Z, CPT> G;
     enum { NS = G::NS, CH = PLANES_CH, NCH = NS / CH };
     const float INF = __uint_as_float(0x7f800000u);
     float min1 = INF, min2 = INF;
     uint32_t idx = 0, R = 0;
-    unsigned long long synd = 0;
+    unsigned long long synd = synd0;     // set for every row if rows have an odd number of missing edges (each reads as hard decision 1)
     // Software pipeline over chunks of CH edges: the LDS reads of chunk k+1 are in flight
     // while chunk k is reduced, so a wave's own LDS latency is covered even when its three
     // SIMD neighbours are waiting too (right after a barrier all of them are).
@@ -187,13 +194,14 @@ __device__ __forceinline__ float planes_phi(float x)
 // pass; the message slot of an edge holds F_e = phi|v_e| between the two halves.
 template <int Z, int CPT, int B, bool FIRST>
 __device__ __forceinline__ unsigned long long
-planes_check_pass_spa(unsigned char *smem, const uint32_t (&radr)[CPT * 4], int D, int sign_mode)
+planes_check_pass_spa(unsigned char *smem, const uint32_t (&radr)[CPT * 4], int D, int sign_mode,
+                      unsigned long long synd0)
 {
     typedef PlanesGeom<Z, CPT> G;
     enum { NS = G::NS, CH = 4, NCH = NS / CH };
     float F1 = 0.0f, rest = 0.0f;          // F > 0 always, so the first edge displaces the initial 0 (rest += 0)
     uint32_t idx = 0, R = 0;
-    unsigned long long synd = 0;
+    unsigned long long synd = synd0;     // set for every row if rows have an odd number of missing edges (each reads as hard decision 1)
     float p[2][CH], c[2][CH];
 #pragma unroll
     for (int k = -1; k < NCH; ++k) {
@@ -275,7 +283,7 @@ planes_check_pass_spa(unsigned char *smem, const uint32_t (&radr)[CPT * 4], int 
 // carries every per-edge intermediate across the merge in registers.
 template <int Z, int CPT, int B, bool SPA>
 __device__ __forceinline__ void
-planes_role(unsigned char *smem, const RegTables &tb, const DecodeArgs &a)
+planes_role(unsigned char *smem, const PlanesTables &tb, const DecodeArgs &a)
 {
     typedef PlanesGeom<Z, CPT> G;
     enum { MB = G::MB, W = G::W, NB = G::NB, NS = G::NS, N = G::N, ZP = G::ZP, CB = G::CB,
@@ -295,8 +303,9 @@ planes_role(unsigned char *smem, const RegTables &tb, const DecodeArgs &a)
 
     // ---- per-launch set-up
     for (int x = tid; x < MB * NB * W; x += NT) shtab[x] = tb.shifts[x];
-    const uint32_t rmask = g == 0 ? tb.row_mask[0] : tb.row_mask[1];     // present circulants of my block-row
-    const int D = __popc(rmask) * W;
+    const uint32_t emask = g == 0 ? tb.edge_mask[0] : tb.edge_mask[1];   // existing edges of a row of my block-row
+    const int D = __popc(emask);
+    const unsigned long long synd0 = ((NS - D) & 1) ? __ballot(live) : 0ull;   // only lanes that own a row
     // once per launch: message slots (those of zeroed circulants are never written again) and the dummy record
     for (int x = tid; x < N; x += NT)
 #pragma unroll
@@ -309,7 +318,7 @@ planes_role(unsigned char *smem, const RegTables &tb, const DecodeArgs &a)
         int c = ic + sh;
         c = c >= Z ? c - Z : c;
         // laundered: otherwise the per-block constant is split off and re-added at every use
-        radr[s] = opaque(((rmask >> (s >> 1)) & 1u) ? (uint32_t)((s >> 1) * Z + c) * CB : (uint32_t)G::DUMMY_OFF);
+        radr[s] = opaque(((emask >> s) & 1u) ? (uint32_t)((s >> 1) * Z + c) * CB : (uint32_t)G::DUMMY_OFF);
     }
     // my columns: block-column g + q*MB, position ic; records q and q+4 share a base register
     const uint32_t cadr0 = (uint32_t)(g * Z + ic) * CB;
@@ -420,8 +429,8 @@ planes_role(unsigned char *smem, const RegTables &tb, const DecodeArgs &a)
         {
             if (live) {
                 const unsigned long long synd = SPA
-                    ? planes_check_pass_spa<Z, CPT, B, true>(smem, radr, D, a.sign_mode)
-                    : planes_check_pass<Z, CPT, B, true>(smem, radr, D, a.sign_mode, ic);
+                    ? planes_check_pass_spa<Z, CPT, B, true>(smem, radr, D, a.sign_mode, synd0)
+                    : planes_check_pass<Z, CPT, B, true>(smem, radr, D, a.sign_mode, ic, synd0);
                 if (synd != 0ull) flags[0] = 1;
             }
             TRACE(4);
@@ -438,8 +447,8 @@ planes_role(unsigned char *smem, const RegTables &tb, const DecodeArgs &a)
                     const int par = it & 1;
                     if (live) {
                         const unsigned long long synd = SPA
-                            ? planes_check_pass_spa<Z, CPT, B, false>(smem, radr, D, a.sign_mode)
-                            : planes_check_pass<Z, CPT, B, false>(smem, radr, D, a.sign_mode, ic);
+                            ? planes_check_pass_spa<Z, CPT, B, false>(smem, radr, D, a.sign_mode, synd0)
+                            : planes_check_pass<Z, CPT, B, false>(smem, radr, D, a.sign_mode, ic, synd0);
                         if (synd != 0ull) flags[par] = 1;
                     }
                     lds_barrier();
@@ -520,7 +529,7 @@ planes_role(unsigned char *smem, const RegTables &tb, const DecodeArgs &a)
 
 template <int Z, int CPT, bool SPA>
 __global__ void __launch_bounds__(1024)
-qc_planes_kernel(const RegTables tb, const DecodeArgs a)
+qc_planes_kernel(const PlanesTables tb, const DecodeArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (__builtin_amdgcn_readfirstlane(threadIdx.x / PlanesGeom<Z, CPT>::ZP) == 0)

@@ -371,3 +371,42 @@ def test_full_size_batch_properties(engines):
     assert float(both.float().mean()) > 0.99
     assert torch.equal(hd64[both], hard[:S][both])
     assert float((it64[both] == iters[:S][both]).float().mean()) > 0.999   # rounding may move a frame by one iteration
+
+
+def test_light_circulants_on_the_message_plane_kernel(oracle_mod):
+    """Circulants of weight 0, 1 and 2 mixed (what a gym action with at most two hot bits, or a
+    swap of two circulants, produces): float32 runs on the message-plane kernel with the
+    missing edges parked on a dummy record -- odd and even numbers of them per row, in both
+    block-rows -- and must stay bit-identical to the oracle, for both sign rules."""
+    import ldpc_amd
+    from ldpc_amd import codes
+    base = codes.near_earth()
+    variants = [
+        base.with_block(1, 9, [42]),                                            # one edge missing in block-row 1
+        base.with_block(0, 0, [7]).with_block(0, 15, []).with_block(1, 3, [500]).with_block(1, 4, [0, 510]),
+        base.with_block(0, 5, base.blocks[1][6]).with_block(1, 6, base.blocks[0][5]),   # a swap: still all weight 2
+    ]
+    for qc in variants:
+        H = qc.to_dense()
+        orc = oracle_mod.Oracle(H)
+        Y = make_llrs(1234, 3.3, qc.n, 20)
+        Y[3, :40] = 0.0                                                          # erased symbols: exact zeros
+        with ldpc_amd.Decoder(qc) as eng:
+            assert eng.launch_info(prec=32)['lds_bytes'] == 163824              # the message-plane kernel
+            for sm in (0, 1):
+                hard, iters, conv, soft = orc.minsum(Y, 50, prec=32, sign_mode=sm, threads=8)
+                r = eng.decode(Y, 50, prec=32, sign_mode=sm, want_soft=True)
+                assert np.array_equal(r['iters'], iters), (qc.row_degrees(), sm, r['iters'], iters)
+                assert np.array_equal(r['converged'], conv) and np.array_equal(r['hard'], hard)
+                assert np.array_equal(r['soft'], soft)
+            # float64 of the same code goes through the table-driven kernel
+            h64, i64, c64, s64 = orc.minsum(Y, 50, prec=64, threads=8)
+            r = eng.decode(Y, 50, prec=64, want_soft=True)
+            assert np.array_equal(r['iters'], i64) and np.array_equal(r['soft'], s64)
+            # sum-product on the same planes (corrected sign rule: some rows have odd degree)
+            scale = np.float32(4 * 10 ** 0.33)
+            hs, is_, cs, _ = orc.spa(Y, float(scale), 50, prec=32, sign_mode=1, want_soft=False, threads=8)
+            r = eng.decode(Y * scale, 50, prec=32, algo=ldpc_amd.ALGO_SUMPRODUCT, sign_mode=1)
+            cv = cs == 1
+            assert cv.sum() >= 15
+            assert np.array_equal(r['iters'][cv], is_[cv]) and np.array_equal(r['hard'][cv], hs[cv])
