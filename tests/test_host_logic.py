@@ -96,7 +96,7 @@ def test_hot_position_file_round_trip(tmp_path):
     assert np.array_equal(fileHandler.hotLocationsToCirculant([0, 3], 5),
                           np.array([[1, 0, 0, 1, 0], [0, 1, 0, 0, 1], [1, 0, 1, 0, 0],
                                     [0, 1, 0, 1, 0], [0, 0, 1, 0, 1]]))
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError):        # a hot-position file is not a hexadecimal generator file
         fileHandler.readMatrixFromFile(str(p), 7154, 8176, 511, True, True, True)
 
 
