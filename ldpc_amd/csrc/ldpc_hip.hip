@@ -663,12 +663,14 @@ __device__ __forceinline__ float4 normal4(uint64_t seed, uint64_t frame, uint32_
 {
     const uint4 r = philox4x32_10(make_uint4(q, (uint32_t)frame, (uint32_t)(frame >> 32), stream),
                                   make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
-    const float r0 = sqrtf(-2.0f * logf(u01(r.x)));
-    const float r1 = sqrtf(-2.0f * logf(u01(r.z)));
-    float s0, c0, s1, c1;
-    sincospif(2.0f * u01(r.y), &s0, &c0);
-    sincospif(2.0f * u01(r.w), &s1, &c1);
-    return make_float4(r0 * c0, r0 * s0, r1 * c1, r1 * s1);
+    // Box-Muller on the hardware transcendental units (log2, sqrt, and sin/cos that take their
+    // argument in revolutions): absolute error ~1e-6, far below the Monte-Carlo resolution,
+    // at a third of the instructions of the library routines
+    const float r0 = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u01(r.x)));   // -2 ln u = -2 ln2 log2 u
+    const float r1 = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u01(r.z)));
+    const float a0 = u01(r.y), a1 = u01(r.w);
+    return make_float4(r0 * __builtin_amdgcn_cosf(a0), r0 * __builtin_amdgcn_sinf(a0),
+                       r1 * __builtin_amdgcn_cosf(a1), r1 * __builtin_amdgcn_sinf(a1));
 }
 
 // y = -1 + sigma*z for the all-zero codeword (modulate: 0 -> -1, ldpc.py:62-66;
