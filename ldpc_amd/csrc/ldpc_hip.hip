@@ -1531,7 +1531,7 @@ extern "C" int ldpc_eval_awgn(ldpc_handle *h, int algo, int prec, int sign_mode,
     if (n_snr == 0 || frames_per_snr == 0) return 0;
     HIP_TRY(hipSetDevice(h->device));
     const size_t n = (size_t)h->n;
-    const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(frames_per_snr, (int64_t)((1024u << 20) / (n * 4)) + 1));
+    const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(frames_per_snr, (int64_t)(((size_t)8192 << 20) / (n * 4)) + 1));
     if ((rc = h->b_llr.ensure((size_t)chunk * n * 4)) || (rc = h->b_iters.ensure((size_t)chunk * 4)) ||
         (rc = h->b_conv.ensure((size_t)chunk)) || (rc = h->b_ones.ensure((size_t)chunk * 4)) ||
         (rc = h->b_sig.ensure((size_t)chunk * 4)) || (rc = h->b_unc.ensure((size_t)chunk * 4)) ||
