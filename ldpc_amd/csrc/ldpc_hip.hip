@@ -82,6 +82,8 @@ struct DecodeArgs {
     unsigned char *chain;  // null, or the persistent check-node state of a chained decoder:
                            // frames are decoded one after another (grid of 1 workgroup) and the
                            // check rows' last outgoing messages carry over from frame to frame
+    int *work;             // null, or a zeroed counter: workgroups claim frames gridDim.x + atomicAdd(work, 1)
+                           // one at a time instead of walking a fixed stride (message-plane kernel)
 };
 
 // ---------------------------------------------------------------- small helpers
@@ -794,7 +796,7 @@ struct ldpc_handle {
     int max_col_deg = 0, min_row_deg = 0;
     std::vector<void *> tables;   // device allocations owned by the handle
     // staging for the host entry points
-    DevBuf b_llr, b_hard, b_iters, b_conv, b_ones, b_soft, b_sig, b_unc, b_cnt, b_pf, b_ws;
+    DevBuf b_llr, b_hard, b_iters, b_conv, b_ones, b_soft, b_sig, b_unc, b_cnt, b_pf, b_ws, b_work;
     // check-node state of the chained (stateful) decoder, one per arithmetic width
     DevBuf b_chain32, b_chain64;
 };
@@ -859,7 +861,7 @@ extern "C" void ldpc_destroy(ldpc_handle *h)
     if (h->own_stream) { (void)hipStreamSynchronize(h->own_stream); }
     for (void *p : h->tables) (void)hipFree(p);
     DevBuf *bufs[] = {&h->b_llr, &h->b_hard, &h->b_iters, &h->b_conv, &h->b_ones, &h->b_soft,
-                      &h->b_sig, &h->b_unc, &h->b_cnt, &h->b_pf, &h->b_ws, &h->b_chain32, &h->b_chain64};
+                      &h->b_sig, &h->b_unc, &h->b_cnt, &h->b_pf, &h->b_ws, &h->b_chain32, &h->b_chain64, &h->b_work};
     for (DevBuf *b : bufs) b->release();
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
@@ -1332,6 +1334,14 @@ static int launch_decode(ldpc_handle *h, int algo, int prec, const DecodeArgs &a
     } else if (L.planes) {
         PlanesTables tb = h->planes;
         DecodeArgs a = args;
+        // frames are claimed one at a time from a counter: they differ in iteration count, and
+        // a fixed share per workgroup leaves most CUs idle while the unluckiest one finishes
+        const char *fixed = getenv("LDPC_HIP_STATIC_FRAMES");
+        if (a.n_frames < (int64_t)0x7fffffff - L.grid && !(fixed && fixed[0] == '1')) {
+            if ((rc = h->b_work.ensure(256))) return rc;
+            HIP_TRY(hipMemsetAsync(h->b_work.p, 0, 4, h->stream));
+            a.work = reinterpret_cast<int *>(h->b_work.p);
+        }
         void *kargs[] = {&tb, &a};
         HIP_TRY(hipLaunchKernel(L.fn, dim3(L.grid), dim3(L.block), kargs, L.lds, h->stream));
     } else if (algo == LDPC_ALGO_SUMPRODUCT) {
@@ -1403,7 +1413,7 @@ extern "C" int ldpc_decode_device(ldpc_handle *h, int algo, int prec, int sign_m
     DecodeArgs a;
     a.llr = d_llr; a.llr_f64 = llr_bits == 64; a.llr_scale = llr_scale; a.n_frames = n_frames; a.max_iters = max_iters;
     a.sign_mode = sign_mode; a.hard = d_hard_bits; a.iters = d_iters; a.conv = d_converged;
-    a.ones = d_ones; a.soft = d_soft_out; a.chain = nullptr;
+    a.ones = d_ones; a.soft = d_soft_out; a.chain = nullptr; a.work = nullptr;
     return launch_decode(h, algo, prec, a);
 }
 
@@ -1465,7 +1475,7 @@ static int decode_host(ldpc_handle *h, bool chained, int algo, int prec, int sig
         a.conv = reinterpret_cast<uint8_t *>(h->b_conv.p);
         a.ones = reinterpret_cast<int32_t *>(h->b_ones.p);
         a.soft = soft_out ? h->b_soft.p : nullptr;
-        a.chain = chain;
+        a.chain = chain; a.work = nullptr;
         if ((rc = launch_decode(h, algo, prec, a))) return rc;
         if (hard_bits) HIP_TRY(hipMemcpyAsync(hard_bits + (size_t)f0 * nbytes, h->b_hard.p, (size_t)nf * nbytes, hipMemcpyDeviceToHost, h->stream));
         if (iters) HIP_TRY(hipMemcpyAsync(iters + f0, h->b_iters.p, (size_t)nf * 4, hipMemcpyDeviceToHost, h->stream));
@@ -1556,7 +1566,7 @@ extern "C" int ldpc_eval_awgn(ldpc_handle *h, int algo, int prec, int sign_mode,
             a.iters = reinterpret_cast<int32_t *>(h->b_iters.p);
             a.conv = reinterpret_cast<uint8_t *>(h->b_conv.p);
             a.ones = reinterpret_cast<int32_t *>(h->b_ones.p);
-            a.soft = nullptr; a.chain = nullptr;
+            a.soft = nullptr; a.chain = nullptr; a.work = nullptr;
             if ((rc = launch_decode(h, algo, prec, a))) return rc;
             const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((nf + 255) / 256, 1024));
             hipLaunchKernelGGL(accumulate_kernel, dim3(grid), dim3(256), 0, h->stream, nf,

@@ -410,7 +410,7 @@ planes_role(unsigned char *smem, const PlanesTables &tb, const DecodeArgs &a)
 #else
 #define TRACE(k)
 #endif
-    for (int64_t frame = blockIdx.x; frame < n_frames; frame += gridDim.x) {
+    for (int64_t frame = blockIdx.x, next_frame = 0; frame < n_frames; frame = next_frame) {
         TRACE(0);
 #pragma unroll
         for (int q = 0; q < CPT; ++q)
@@ -420,8 +420,9 @@ planes_role(unsigned char *smem, const PlanesTables &tb, const DecodeArgs &a)
         TRACE(1);
         lds_barrier();
         TRACE(2);
-        if (live && frame + gridDim.x < n_frames)
-            planes_load_frame<CPT>(a.llr, a.llr_f64, (frame + gridDim.x) * N, (uint32_t)(g * Z + ic), MB * Z, ynext);
+        // claim the frame after this one; the answer is needed only after the check pass below
+        int claimed = 0;
+        if (a.work && tid == 0) claimed = atomicAdd(a.work, 1);
         flush_outputs();
         TRACE(3);
 
@@ -433,9 +434,15 @@ planes_role(unsigned char *smem, const PlanesTables &tb, const DecodeArgs &a)
                     : planes_check_pass<Z, CPT, B, true>(smem, radr, D, a.sign_mode, ic, synd0);
                 if (synd != 0ull) flags[0] = 1;
             }
+            if (a.work && tid == 0) flags[3] = claimed;
             TRACE(4);
             lds_barrier();
             TRACE(5);
+            next_frame = frame + gridDim.x;
+            if (a.work) next_frame = (int64_t)gridDim.x + __builtin_amdgcn_readfirstlane(flags[3]);
+            // the next frame's channel values: requested now, used when this frame is done
+            if (live && next_frame < n_frames)
+                planes_load_frame<CPT>(a.llr, a.llr_f64, next_frame * N, (uint32_t)(g * Z + ic), MB * Z, ynext);
             const int bad = __builtin_amdgcn_readfirstlane(flags[0]);
             if (bad == 0 || a.max_iters <= 0) {
                 my_conv = (bad == 0);
