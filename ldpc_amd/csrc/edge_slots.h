@@ -27,14 +27,15 @@ struct SlotTables {
 
 struct SlotGeom {
     enum { CB = 20, YMAX = 8 };
-    uint32_t y_off, flag_off, cont_off, ones_off, dummy_off, bytes;
+    uint32_t y_off, flag_off, cont_off, claim_off, ones_off, dummy_off, bytes;
     __host__ __device__ SlotGeom(int n, int F)
     {
         const uint32_t cols = (uint32_t)n * (uint32_t)F;
         y_off = cols * CB;
         flag_off = y_off + cols * 4;          // [2][F] "syndrome of frame non-zero"
         cont_off = flag_off + 2u * F * 4;     // [2]    "some frame goes on"
-        ones_off = cont_off + 8;              // [F]
+        claim_off = cont_off + 8;             // [1]    block of frames this workgroup decodes after the next one
+        ones_off = claim_off + 8;             // [F]
         dummy_off = ones_off + (uint32_t)F * 4;
         bytes = (dummy_off + CB + 15) / 16 * 16;
     }
@@ -105,7 +106,12 @@ slot_minsum_kernel(const SlotTables tb, const DecodeArgs a)
     };
     if ((int64_t)blockIdx.x < n_fblocks && !a.llr_f64) fetch(blockIdx.x, ypf);
 
-    for (int64_t fb = blockIdx.x; fb < n_fblocks; fb += gridDim.x) {
+    // Blocks of frames are claimed from a device counter when a.work is set (frames differ in
+    // iteration count; a fixed stride leaves CUs idle at the end of a launch).  The claim is made
+    // two blocks ahead, so its latency and the prefetch of the next block never wait for it.
+    int *claim_word = reinterpret_cast<int *>(smem + G.claim_off);
+    int64_t fb_next = (int64_t)blockIdx.x + gridDim.x;
+    for (int64_t fb = blockIdx.x; fb < n_fblocks;) {
         if (a.llr_f64) fetch(fb, ypf);
         const int64_t my_frame = fb * F + f;
         bool my_act = row_valid && my_frame < a.n_frames;
@@ -127,7 +133,9 @@ slot_minsum_kernel(const SlotTables tb, const DecodeArgs a)
         if (tid < F) ones_cnt[tid] = 0;
         int my_iters = 0, my_conv = 0;
         lds_barrier();
-        if (fb + gridDim.x < n_fblocks && !a.llr_f64) fetch(fb + gridDim.x, ypf);
+        int claimed = 0;
+        if (a.work && tid == 0) claimed = atomicAdd(a.work, 1);
+        if (fb_next < n_fblocks && !a.llr_f64) fetch(fb_next, ypf);
 
         for (int it = 0;; ++it) {
             const int par = it & 1;
@@ -278,12 +286,17 @@ slot_minsum_kernel(const SlotTables tb, const DecodeArgs a)
             for (int cg = tid; cg < cols; cg += NT)
                 if (base + cg < total) reinterpret_cast<float *>(a.soft)[base + cg] = lds_f32(smem, (uint32_t)cg * CB);
         }
+        if (a.work && tid == 0) *claim_word = claimed;
         lds_barrier();
         if (row_valid && r == 0 && my_frame < a.n_frames) {
             if (a.iters) a.iters[my_frame] = my_iters;
             if (a.conv) a.conv[my_frame] = (uint8_t)my_conv;
             if (a.ones) a.ones[my_frame] = ones_cnt[f];
         }
+        const int64_t after = a.work ? 2 * (int64_t)gridDim.x + __builtin_amdgcn_readfirstlane(*claim_word)
+                                     : fb_next + gridDim.x;
         lds_barrier();
+        fb = fb_next;
+        fb_next = after;
     }
 }

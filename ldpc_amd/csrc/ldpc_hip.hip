@@ -1319,6 +1319,21 @@ static size_t chain_bytes(const ldpc_handle *h, int prec)
     return (size_t)h->qc.mb * h->qc.Zp * 32;   // covers the state layout of either QC kernel
 }
 
+// Frames (or blocks of frames) are claimed from a zeroed device counter: they differ in
+// iteration count, and a fixed share per workgroup leaves most CUs idle while the unluckiest
+// one finishes.  LDPC_HIP_STATIC_FRAMES=1 keeps the fixed stride.
+static int claim_counter(ldpc_handle *h, const Launch &L, DecodeArgs *a)
+{
+    const char *fixed = getenv("LDPC_HIP_STATIC_FRAMES");
+    a->work = nullptr;
+    if (a->n_frames >= (int64_t)0x7fffffff - 4 * (int64_t)L.grid || (fixed && fixed[0] == '1')) return 0;
+    int rc = h->b_work.ensure(256);
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(h->b_work.p, 0, 4, h->stream));
+    a->work = reinterpret_cast<int *>(h->b_work.p);
+    return 0;
+}
+
 static int launch_decode(ldpc_handle *h, int algo, int prec, const DecodeArgs &args)
 {
     Launch L;
@@ -1329,19 +1344,13 @@ static int launch_decode(ldpc_handle *h, int algo, int prec, const DecodeArgs &a
         tb.m = h->m; tb.n = h->n; tb.E = h->E; tb.F = L.fpw;
         tb.row_ptr = h->csr.row_ptr; tb.col_idx = h->csr.col_idx; tb.edge_slot = h->edge_slot;
         DecodeArgs a = args;
+        if ((rc = claim_counter(h, L, &a))) return rc;
         void *kargs[] = {&tb, &a};
         HIP_TRY(hipLaunchKernel(L.fn, dim3(L.grid), dim3(L.block), kargs, L.lds, h->stream));
     } else if (L.planes) {
         PlanesTables tb = h->planes;
         DecodeArgs a = args;
-        // frames are claimed one at a time from a counter: they differ in iteration count, and
-        // a fixed share per workgroup leaves most CUs idle while the unluckiest one finishes
-        const char *fixed = getenv("LDPC_HIP_STATIC_FRAMES");
-        if (a.n_frames < (int64_t)0x7fffffff - L.grid && !(fixed && fixed[0] == '1')) {
-            if ((rc = h->b_work.ensure(256))) return rc;
-            HIP_TRY(hipMemsetAsync(h->b_work.p, 0, 4, h->stream));
-            a.work = reinterpret_cast<int *>(h->b_work.p);
-        }
+        if ((rc = claim_counter(h, L, &a))) return rc;
         void *kargs[] = {&tb, &a};
         HIP_TRY(hipLaunchKernel(L.fn, dim3(L.grid), dim3(L.block), kargs, L.lds, h->stream));
     } else if (algo == LDPC_ALGO_SUMPRODUCT) {
