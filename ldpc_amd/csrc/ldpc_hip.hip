@@ -1144,7 +1144,7 @@ static int reg_pick(const ldpc_handle *h, Launch *L)
     L->fpw = FPW;
     const size_t slots = (size_t)FPW * MB * h->reg.Zp;
     size_t b = (((size_t)FPW * h->reg.n * sizeof(T)) + 15) & ~(size_t)15;
-    b += slots * RegState<T>::BYTES + 3 * FPW * sizeof(int);
+    b += slots * RegState<T>::BYTES + (3 * FPW + 1) * sizeof(int);
     L->lds = (b + 15) & ~(size_t)15;
     return 0;
 }
@@ -1365,6 +1365,7 @@ static int launch_decode(ldpc_handle *h, int algo, int prec, const DecodeArgs &a
     } else if (h->is_qc && h->is_regular) {
         RegTables tb = h->reg;
         DecodeArgs a = args;
+        if (!a.chain && (rc = claim_counter(h, L, &a))) return rc;      // a re-used decoder takes its frames in order
         void *kargs[] = {&tb, &a};
         HIP_TRY(hipLaunchKernel(L.fn, dim3(L.grid), dim3(L.block), kargs, L.lds, h->stream));
     } else if (h->is_qc) {

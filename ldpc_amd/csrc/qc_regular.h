@@ -131,6 +131,7 @@ qc_regular_kernel(const RegTables tb, const DecodeArgs a)
     const uint32_t post_rel = sizeof(T) == 8 ? post_off : 0u;   // added when a packed posterior address is used
     int *flags = reinterpret_cast<int *>(smem + flag_off);   // [2][FPW] "syndrome non-zero"
     int *ones_cnt = flags + 2 * FPW;                          // [FPW]
+    int *claim_word = flags + 3 * FPW;                        // [1] block of frames decoded after the next one
 
     const int tid = threadIdx.x;
     const int grp = __builtin_amdgcn_readfirstlane(tid / Zp);
@@ -216,7 +217,10 @@ qc_regular_kernel(const RegTables tb, const DecodeArgs a)
             for (int q = 0; q < CPT; ++q) ypf[q] = src[(int64_t)q * (MB * Z)];
         }
     }
-    for (int64_t fb = blockIdx.x; fb < n_fblocks; fb += gridDim.x) {
+    // With a.work set, blocks of frames are claimed from a device counter two blocks ahead
+    // (frames differ in iteration count; a fixed stride leaves CUs idle at the end of a launch).
+    int64_t fb_next = (int64_t)blockIdx.x + gridDim.x;
+    for (int64_t fb = blockIdx.x; fb < n_fblocks;) {
         const int64_t frame = fb * FPW + f;
         const bool valid = frame < a.n_frames;
         T y[CPT];
@@ -246,8 +250,10 @@ qc_regular_kernel(const RegTables tb, const DecodeArgs a)
         // Next frame's channel values: requested here, not before the barrier.  A CU needs
         // thousands of cycles to queue a frame's worth of loads; after the barrier that
         // queueing overlaps the other waves' first check pass instead of idling the CU.
+        int claimed = 0;
+        if (a.work && tid == 0) claimed = atomicAdd(a.work, 1);
         {
-            const int64_t fbn = fb + gridDim.x;
+            const int64_t fbn = fb_next;
             const int64_t framen = fbn * FPW + f;
             if (!a.llr_f64 && live && fbn < n_fblocks && framen < a.n_frames) {
                 const float *src = reinterpret_cast<const float *>(a.llr) + framen * n + g * Z + i;
@@ -406,13 +412,18 @@ qc_regular_kernel(const RegTables tb, const DecodeArgs a)
                 so[j * Z + i] = post[fbase + j * Z + i];
             }
         }
+        if (a.work && tid == 0) *claim_word = claimed;
         lds_barrier();
         if (valid && g == 0 && i == 0) {
             if (a.iters) a.iters[frame] = my_iters;
             if (a.conv) a.conv[frame] = (uint8_t)my_conv;
             if (a.ones) a.ones[frame] = ones_cnt[f];
         }
+        const int64_t after = a.work ? 2 * (int64_t)gridDim.x + __builtin_amdgcn_readfirstlane(*claim_word)
+                                     : fb_next + gridDim.x;
         lds_barrier();
+        fb = fb_next;
+        fb_next = after;
     }
     if (chain && live) {
         unsigned char *dst = chain + (size_t)(grp * Zp + i) * 32;
