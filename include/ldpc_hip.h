@@ -83,6 +83,13 @@ void ldpc_destroy(ldpc_handle *h);
 /* Code dimensions of a handle. */
 int ldpc_get_dims(const ldpc_handle *h, int *m, int *n, int *edges);
 
+/* Min-sum magnitude correction for every later min-sum decode on this handle:
+ * |check-to-variable message| = max(alpha * min - beta, 0) (normalised and/or offset min-sum).
+ * The default alpha = 1, beta = 0 is the reference's plain rule (ldpc.py:174-202) and leaves
+ * every result bit-identical; the reference has no counterpart for other values (an optional
+ * decoder variant).  Needs alpha > 0, beta >= 0. */
+int ldpc_set_minsum_scaling(ldpc_handle *h, float alpha, float beta);
+
 /* Make the handle launch on an existing HIP stream: hip_stream is a hipStream_t
  * passed as void* (NULL is the legacy default stream, which is a valid choice);
  * use_own != 0 ignores hip_stream and goes back to the stream the handle

@@ -178,6 +178,10 @@ slot_minsum_kernel(const SlotTables tb, const DecodeArgs a)
                 uint32_t S = __popc(R) & 1u;                                        // spare edges are positive
                 if (a.sign_mode == LDPC_SIGN_CORRECTED) S ^= (uint32_t)deg & 1u;
                 const uint32_t T = R ^ (S ? (0xffffffffu << (32 - DC)) : 0u);
+                if (a.ms_alpha != 1.0f || a.ms_beta != 0.0f) {
+                    min1 = ms_correct(min1, a.ms_alpha, a.ms_beta);
+                    min2 = ms_correct(min2, a.ms_alpha, a.ms_beta);
+                }
                 const uint32_t m1 = __float_as_uint(min1), m2 = __float_as_uint(min2);
                 set_wave_prio(0);
 #pragma unroll

@@ -82,6 +82,7 @@ struct DecodeArgs {
     unsigned char *chain;  // null, or the persistent check-node state of a chained decoder:
                            // frames are decoded one after another (grid of 1 workgroup) and the
                            // check rows' last outgoing messages carry over from frame to frame
+    float ms_alpha, ms_beta;   // min-sum magnitude correction: |c2v| = max(alpha*min - beta, 0); 1, 0 = the reference's plain rule
     int *work;             // null, or a zeroed counter: workgroups claim frames gridDim.x + atomicAdd(work, 1)
                            // one at a time instead of walking a fixed stride (message-plane kernel)
 };
@@ -136,6 +137,11 @@ __device__ __forceinline__ float t_inf(float) { return __uint_as_float(0x7f80000
 __device__ __forceinline__ double t_inf(double) { return __hiloint2double(0x7ff00000, 0); }
 __device__ __forceinline__ float t_abs(float x) { return fabsf(x); }
 __device__ __forceinline__ double t_abs(double x) { return fabs(x); }
+
+// normalised / offset min-sum magnitude (applied once per check row to min1 and min2);
+// alpha = 1, beta = 0 leaves every value unchanged bit for bit
+__device__ __forceinline__ float ms_correct(float m, float alpha, float beta) { return fmaxf(alpha * m - beta, 0.0f); }
+__device__ __forceinline__ double ms_correct(double m, float alpha, float beta) { return fmax((double)alpha * m - (double)beta, 0.0); }
 
 // second-smallest update: new min2 given min1 <= min2 and a candidate a
 __device__ __forceinline__ float t_mid(float min1, float min2, float a)
@@ -287,6 +293,8 @@ qc_minsum_kernel(const QcTables tb, const DecodeArgs a)
                 if (a.sign_mode == LDPC_SIGN_CORRECTED) S ^= (uint32_t)deg & 1u;
                 const ST full = (deg >= (int)(8 * sizeof(ST))) ? ~(ST)0 : ((((ST)1) << deg) - 1);
                 ns ^= S ? full : (ST)0;
+                min1 = ms_correct(min1, a.ms_alpha, a.ms_beta);
+                min2 = ms_correct(min2, a.ms_alpha, a.ms_beta);
                 T2 mm; mm.x = min1; mm.y = min2;
                 mins[slot] = mm;
                 Meta mt; mt.signs = ns; mt.idx = idx;
@@ -492,6 +500,8 @@ csr_minsum_kernel(const CsrTables tb, const DecodeArgs a, unsigned char *workspa
                 if (a.sign_mode == LDPC_SIGN_CORRECTED) S ^= (uint32_t)deg & 1u;
                 const uint64_t full = (deg >= 64) ? ~0ull : ((1ull << deg) - 1);
                 ns ^= S ? full : 0ull;
+                min1 = ms_correct(min1, a.ms_alpha, a.ms_beta);
+                min2 = ms_correct(min2, a.ms_alpha, a.ms_beta);
                 T2 mm; mm.x = min1; mm.y = min2;
                 mins[r] = mm;
                 Meta mt; mt.signs = ns; mt.idx = idx; mt.pad = 0;
@@ -788,6 +798,7 @@ struct ldpc_handle {
     int reg_w = 0;
     RegTables reg{};
     // message-plane kernel (2 x 16 circulants of size 511, every weight <= 2)
+    float ms_alpha = 1.0f, ms_beta = 0.0f;     // min-sum magnitude correction (ldpc_set_minsum_scaling)
     bool planes_ok = false;
     PlanesTables planes{};
     // CSR
@@ -1079,6 +1090,16 @@ extern "C" int ldpc_get_dims(const ldpc_handle *h, int *m, int *n, int *edges)
     if (m) *m = h->m;
     if (n) *n = h->n;
     if (edges) *edges = h->E;
+    return 0;
+}
+
+extern "C" int ldpc_set_minsum_scaling(ldpc_handle *h, float alpha, float beta)
+{
+    if (!h) return fail(LDPC_E_ARG, "handle is NULL");
+    if (!(alpha > 0.0f) || !(beta >= 0.0f) || !(alpha <= 1e6f) || !(beta <= 1e6f))
+        return fail(LDPC_E_ARG, "need alpha > 0 and beta >= 0");
+    h->ms_alpha = alpha;
+    h->ms_beta = beta;
     return 0;
 }
 
@@ -1424,6 +1445,7 @@ extern "C" int ldpc_decode_device(ldpc_handle *h, int algo, int prec, int sign_m
     a.llr = d_llr; a.llr_f64 = llr_bits == 64; a.llr_scale = llr_scale; a.n_frames = n_frames; a.max_iters = max_iters;
     a.sign_mode = sign_mode; a.hard = d_hard_bits; a.iters = d_iters; a.conv = d_converged;
     a.ones = d_ones; a.soft = d_soft_out; a.chain = nullptr; a.work = nullptr;
+    a.ms_alpha = h->ms_alpha; a.ms_beta = h->ms_beta;
     return launch_decode(h, algo, prec, a);
 }
 
@@ -1485,7 +1507,7 @@ static int decode_host(ldpc_handle *h, bool chained, int algo, int prec, int sig
         a.conv = reinterpret_cast<uint8_t *>(h->b_conv.p);
         a.ones = reinterpret_cast<int32_t *>(h->b_ones.p);
         a.soft = soft_out ? h->b_soft.p : nullptr;
-        a.chain = chain; a.work = nullptr;
+        a.chain = chain; a.work = nullptr; a.ms_alpha = h->ms_alpha; a.ms_beta = h->ms_beta;
         if ((rc = launch_decode(h, algo, prec, a))) return rc;
         if (hard_bits) HIP_TRY(hipMemcpyAsync(hard_bits + (size_t)f0 * nbytes, h->b_hard.p, (size_t)nf * nbytes, hipMemcpyDeviceToHost, h->stream));
         if (iters) HIP_TRY(hipMemcpyAsync(iters + f0, h->b_iters.p, (size_t)nf * 4, hipMemcpyDeviceToHost, h->stream));
@@ -1576,7 +1598,7 @@ extern "C" int ldpc_eval_awgn(ldpc_handle *h, int algo, int prec, int sign_mode,
             a.iters = reinterpret_cast<int32_t *>(h->b_iters.p);
             a.conv = reinterpret_cast<uint8_t *>(h->b_conv.p);
             a.ones = reinterpret_cast<int32_t *>(h->b_ones.p);
-            a.soft = nullptr; a.chain = nullptr; a.work = nullptr;
+            a.soft = nullptr; a.chain = nullptr; a.work = nullptr; a.ms_alpha = h->ms_alpha; a.ms_beta = h->ms_beta;
             if ((rc = launch_decode(h, algo, prec, a))) return rc;
             const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((nf + 255) / 256, 1024));
             hipLaunchKernelGGL(accumulate_kernel, dim3(grid), dim3(256), 0, h->stream, nf,

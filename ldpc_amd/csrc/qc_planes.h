@@ -87,7 +87,7 @@ struct PlanesGeom {
 template <int Z, int CPT, int B, bool FIRST>
 __device__ __forceinline__ unsigned long long
 planes_check_pass(unsigned char *smem, const uint32_t (&radr)[CPT * 4], int D, int sign_mode, int ic,
-                  unsigned long long synd0)
+                  unsigned long long synd0, float alpha, float beta)
 {
     typedef PlanesGeom<Z, CPT> G;
     enum { NS = G::NS, CH = PLANES_CH, NCH = NS / CH };
@@ -151,6 +151,10 @@ planes_check_pass(unsigned char *smem, const uint32_t (&radr)[CPT * 4], int D, i
     if (sign_mode == LDPC_SIGN_CORRECTED) S ^= (uint32_t)D & 1u;       // D: the row's real degree
     const uint32_t full = 0xffffffffu << (32 - NS);
     const uint32_t T = R ^ (S ? full : 0u);
+    if (alpha != 1.0f || beta != 0.0f) {                    // normalised / offset min-sum (uniform branch)
+        min1 = ms_correct(min1, alpha, beta);
+        min2 = ms_correct(min2, alpha, beta);
+    }
     const uint32_t m1 = __float_as_uint(min1), m2 = __float_as_uint(min2);
     // shift of the arg-min edge, needed after the loop below (idx differs from lane to lane)
     const uint32_t ej = idx >> 1, ek = idx & 1u;
@@ -431,7 +435,7 @@ planes_role(unsigned char *smem, const PlanesTables &tb, const DecodeArgs &a)
             if (live) {
                 const unsigned long long synd = SPA
                     ? planes_check_pass_spa<Z, CPT, B, true>(smem, radr, D, a.sign_mode, synd0)
-                    : planes_check_pass<Z, CPT, B, true>(smem, radr, D, a.sign_mode, ic, synd0);
+                    : planes_check_pass<Z, CPT, B, true>(smem, radr, D, a.sign_mode, ic, synd0, a.ms_alpha, a.ms_beta);
                 if (synd != 0ull) flags[0] = 1;
             }
             if (a.work && tid == 0) flags[3] = claimed;
@@ -455,7 +459,7 @@ planes_role(unsigned char *smem, const PlanesTables &tb, const DecodeArgs &a)
                     if (live) {
                         const unsigned long long synd = SPA
                             ? planes_check_pass_spa<Z, CPT, B, false>(smem, radr, D, a.sign_mode, synd0)
-                            : planes_check_pass<Z, CPT, B, false>(smem, radr, D, a.sign_mode, ic, synd0);
+                            : planes_check_pass<Z, CPT, B, false>(smem, radr, D, a.sign_mode, ic, synd0, a.ms_alpha, a.ms_beta);
                         if (synd != 0ull) flags[par] = 1;
                     }
                     lds_barrier();

@@ -109,6 +109,11 @@ class Decoder:
         else:
             _check(self._L.ldpc_set_stream(self._h, ctypes.c_void_p(int(hip_stream)), 0))
 
+    def set_minsum_scaling(self, alpha=1.0, beta=0.0):
+        """Normalised / offset min-sum for later decodes: |message| = max(alpha*min - beta, 0).
+        (1, 0) is the reference's plain min-sum."""
+        _check(self._L.ldpc_set_minsum_scaling(self._h, float(alpha), float(beta)))
+
     def sync(self):
         _check(self._L.ldpc_sync(self._h))
 

@@ -99,6 +99,11 @@ static int f32_syndrome_is_zero(const oracle_graph *g, const float *x) { SYNDROM
 #undef PHI
 #undef FN
 
+/* Magnitude correction of the min-sum drivers (1, 0 = the reference's plain rule); float on
+ * purpose: the HIP library takes the two parameters as float. */
+static float oracle_ms_alpha = 1.0f, oracle_ms_beta = 0.0f;
+void oracle_set_minsum_scaling(float alpha, float beta) { oracle_ms_alpha = alpha; oracle_ms_beta = beta; }
+
 /* Batch drivers.  y: [frames][n]; hard: [frames][n] bytes 0/1 or NULL;
  * iters: [frames]; conv: [frames]; soft: [frames][n] or NULL.
  * state: NULL = fresh decoder per frame; else [E] check-to-variable messages of
@@ -106,6 +111,7 @@ static int f32_syndrome_is_zero(const oracle_graph *g, const float *x) { SYNDROM
  * one thread.  threads <= 0 -> 1 thread.  Returns 0, or -1 on allocation failure. */
 #define BATCH_BODY(REAL_T, PFX)                                               \
     int fail = 0;                                                             \
+    const float ms_alpha = oracle_ms_alpha, ms_beta = oracle_ms_beta;         \
     if (threads <= 0 || state) threads = 1;                                   \
     _Pragma("omp parallel num_threads(threads)")                              \
     {                                                                         \
@@ -119,6 +125,7 @@ static int f32_syndrome_is_zero(const oracle_graph *g, const float *x) { SYNDROM
             _Pragma("omp for schedule(dynamic, 1)")                           \
             for (int64_t f = 0; f < n_frames; ++f)                            \
                 PFX##decode_frame(g, sign_mode, state != NULL, max_iters,     \
+                                  (REAL_T)ms_alpha, (REAL_T)ms_beta,          \
                                   y + (size_t)f * g->n,                       \
                                   hard ? hard + (size_t)f * g->n : NULL,      \
                                   iters + f, conv + f,                        \

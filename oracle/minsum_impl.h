@@ -28,8 +28,10 @@
  * edge's own sign, ldpc.py:190-191); sign_mode 1 = additionally multiply by
  * (-1)^degree, which is the textbook rule for the reference's bit polarity
  * (0 -> -1, ldpc.py:62-66); the two coincide for even check degree.
+ * alpha, beta: |c2v| = max(alpha*mag - beta, 0); (1, 0) is the reference's plain rule.
  */
 static void FN(decode_frame)(const oracle_graph *g, int sign_mode, int keep_c2v, int max_iters,
+                             REAL alpha, REAL beta,
                              const REAL *y, uint8_t *hard, int32_t *iters_out,
                              uint8_t *conv_out, REAL *soft_out,
                              REAL *c2v, REAL *v2c, REAL *post)
@@ -66,7 +68,11 @@ static void FN(decode_frame)(const oracle_graph *g, int sign_mode, int keep_c2v,
             if (sign_mode == 1 && ((e1 - e0) & 1)) S = -S;
             for (int e = e0; e < e1; ++e) {
                 const REAL sg = (v2c[e] < (REAL)0) ? (REAL)-1 : (REAL)1;
-                const REAL mag = (e == arg) ? min2 : min1;
+                REAL mag = (e == arg) ? min2 : min1;
+                if (alpha != (REAL)1 || beta != (REAL)0) {         /* normalised / offset variant (not in the reference) */
+                    mag = alpha * mag - beta;
+                    if (!(mag > (REAL)0)) mag = (REAL)0;
+                }
                 c2v[e] = mag * S * sg;                    /* ldpc.py:190-191 */
             }
         }

@@ -42,6 +42,7 @@ def lib():
                 fn = getattr(L, name)
                 fn.restype = ctypes.c_int
         L.oracle_max_threads.restype = ctypes.c_int
+        L.oracle_set_minsum_scaling.argtypes = [ctypes.c_float, ctypes.c_float]
         _LIB = L
     return _LIB
 
@@ -111,15 +112,20 @@ class Oracle:
         """Check-node messages of a freshly built decoder (all zero), for minsum(state=...)."""
         return np.zeros(len(self.col_idx) + 1, np.float64 if prec == 64 else np.float32)
 
-    def minsum(self, y, max_iters=50, prec=64, sign_mode=0, want_soft=True, threads=1, state=None):
+    def minsum(self, y, max_iters=50, prec=64, sign_mode=0, want_soft=True, threads=1, state=None,
+               alpha=1.0, beta=0.0):
         """-> (hard uint8 [F,n], iters int32 [F], converged uint8 [F], soft [F,n] or None).
         state (from new_state, updated in place): decode the frames in order on ONE
         re-used decoder instead of a fresh decoder per frame."""
         dt = np.float64 if prec == 64 else np.float32
         if state is not None:
             assert state.dtype == dt and state.flags.c_contiguous
-        return self._run('oracle_minsum_f64' if prec == 64 else 'oracle_minsum_f32', dt, y, max_iters,
-                         sign_mode, want_soft, threads, state=state)
+        lib().oracle_set_minsum_scaling(float(alpha), float(beta))     # alpha, beta: |c2v| = max(alpha*min - beta, 0)
+        try:
+            return self._run('oracle_minsum_f64' if prec == 64 else 'oracle_minsum_f32', dt, y, max_iters,
+                             sign_mode, want_soft, threads, state=state)
+        finally:
+            lib().oracle_set_minsum_scaling(1.0, 0.0)
 
     def spa(self, y, llr_scale, max_iters=50, prec=64, sign_mode=0, want_soft=True, threads=1):
         """Sum-product (tanh rule) on LLR = llr_scale * y.  No counterpart in the reference."""

@@ -410,3 +410,31 @@ def test_light_circulants_on_the_message_plane_kernel(oracle_mod):
             cv = cs == 1
             assert cv.sum() >= 15
             assert np.array_equal(r['iters'][cv], is_[cv]) and np.array_equal(r['hard'][cv], hs[cv])
+
+
+@pytest.mark.parametrize('name', ['nearEarth', 'wifi_5_6', 'nearEarth_mut_w3', 'rand_24_48'])
+def test_normalised_and_offset_minsum(engines, oracle_mod, name):
+    """Optional decoder variant (no counterpart in the reference, so parity is against this
+    build's oracle only): |message| = max(alpha*min - beta, 0).  Bit-exact in both precisions on
+    every kernel family, and (1, 0) restores the plain rule."""
+    eng = engines(name)
+    _, H = build_code(name)
+    orc = oracle_mod.Oracle(H)
+    pt = next(iter(golden_points(name)))
+    Y = pt['llr'][:12]
+    sm = 1 if name in ('wifi_5_6', 'nearEarth_mut_w3') else 0
+    try:
+        for alpha, beta in ((0.8125, 0.0), (1.0, 0.15), (0.9, 0.05)):
+            eng.set_minsum_scaling(alpha, beta)
+            for prec in (32, 64):
+                hard, iters, conv, soft = orc.minsum(Y, 50, prec=prec, sign_mode=sm, threads=8, alpha=alpha, beta=beta)
+                r = eng.decode(Y, 50, prec=prec, sign_mode=sm, want_soft=True)
+                assert np.array_equal(r['iters'], iters), (name, alpha, beta, prec, r['iters'], iters)
+                assert np.array_equal(r['hard'], hard) and np.array_equal(r['soft'], soft)
+    finally:
+        eng.set_minsum_scaling(1.0, 0.0)
+    hard, iters, conv, soft = orc.minsum(Y, 50, prec=32, sign_mode=sm, threads=8)
+    r = eng.decode(Y, 50, prec=32, sign_mode=sm, want_soft=True)
+    assert np.array_equal(r['iters'], iters) and np.array_equal(r['soft'], soft)
+    with pytest.raises(Exception):
+        eng.set_minsum_scaling(0.0, 0.0)
