@@ -157,7 +157,10 @@ slot_minsum_kernel(const SlotTables tb, const DecodeArgs a)
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     if (k < 0) continue;
-                    if (NCH >= 4 && k % (NCH / 4) == 0) set_wave_prio(3 - k / (NCH / 4) > 0 ? 3 - k / (NCH / 4) : 0);
+                    {
+                        enum { PQ = NCH >= 4 ? NCH / 4 : 1 };            // chunks per priority step
+                        if (NCH >= 4 && k % PQ == 0) set_wave_prio(3 - k / PQ > 0 ? 3 - k / PQ : 0);
+                    }
                     const int cb = k & 1;
 #pragma unroll
                     for (int u = 0; u < CH; ++u) {
