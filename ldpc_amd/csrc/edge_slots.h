@@ -10,7 +10,8 @@
 //   LDS       -> one 20-byte record per column { posterior, message slot 0..3 }, slot k holding
 //               the message of the column's k-th check in ascending check index, so the variable
 //               update is the plain ordered sum of ldpc.py:298-303 (unused slots stay +0);
-//               a plane of channel values; per-frame stop flags and counters; one dummy record.
+//               per-frame stop flags and counters; one dummy record.  The channel values of a
+//               thread's columns stay in its registers.
 // Rows shorter than DC point their spare edges at the dummy record (posterior +inf: never a
 // minimum, sign +, hard decision 1 -- the parity of the spare count is folded into the syndrome).
 // Arithmetic and order are those of the other min-sum kernels (ldpc.py:150-163, 174-202,
@@ -31,8 +32,8 @@ struct SlotGeom {
     __host__ __device__ SlotGeom(int n, int F)
     {
         const uint32_t cols = (uint32_t)n * (uint32_t)F;
-        y_off = cols * CB;
-        flag_off = y_off + cols * 4;          // [2][F] "syndrome of frame non-zero"
+        y_off = cols * CB;                    // (end of the records)
+        flag_off = y_off;                     // [2][F] "syndrome of frame non-zero"
         cont_off = flag_off + 2u * F * 4;     // [2]    "some frame goes on"
         claim_off = cont_off + 8;             // [1]    block of frames this workgroup decodes after the next one
         ones_off = claim_off + 8;             // [F]
@@ -96,9 +97,10 @@ slot_minsum_kernel(const SlotTables tb, const DecodeArgs a)
     auto fetch = [&](int64_t fb, float (&dst)[YMAX]) {
         const int64_t base = fb * F * (int64_t)n;
         const int64_t total = a.n_frames * (int64_t)n;
+        const int t = (int)opaque((uint32_t)tid);             // addresses recomputed here, not kept across the decode
 #pragma unroll
         for (int k = 0; k < YMAX; ++k) {
-            const int cg = k * NT + tid;
+            const int cg = k * NT + t;
             if (cg < cols && base + cg < total)
                 dst[k] = a.llr_f64 ? (float)reinterpret_cast<const double *>(a.llr)[base + cg]
                                    : reinterpret_cast<const float *>(a.llr)[base + cg];
@@ -116,16 +118,16 @@ slot_minsum_kernel(const SlotTables tb, const DecodeArgs a)
         const int64_t my_frame = fb * F + f;
         bool my_act = row_valid && my_frame < a.n_frames;
         // ---- load the block: posterior = channel value, messages = +0 (fresh decoder, ldpc.py:121)
+        float ycur[YMAX];
 #pragma unroll
         for (int k = 0; k < YMAX; ++k) {
             const int cg = k * NT + tid;
+            ycur[k] = ypf[k] * a.llr_scale + 0.0f;                 // "+ 0": -0.0 -> +0.0
             if (cg < cols) {
-                const float yv = ypf[k] * a.llr_scale + 0.0f;      // "+ 0": -0.0 -> +0.0
                 const uint32_t rec = (uint32_t)cg * CB;
-                lds_put_f32(smem, rec, yv);
+                lds_put_f32(smem, rec, ycur[k]);
 #pragma unroll
-                for (int s = 1; s <= 4; ++s) lds_put_f32(smem, rec + 4u * s, 0.0f);
-                lds_put_f32(smem, G.y_off + 4u * (uint32_t)cg, yv);
+                for (int sl = 1; sl <= 4; ++sl) lds_put_f32(smem, rec + 4u * sl, 0.0f);
             }
         }
         if (tid < 2 * F) flags[tid] = 0;
@@ -266,7 +268,7 @@ slot_minsum_kernel(const SlotTables tb, const DecodeArgs a)
                         float acc = lds_f32(smem, rec + 4) + lds_f32(smem, rec + 8);   // 0 + x + y == x + y
                         acc = acc + lds_f32(smem, rec + 12);
                         acc = acc + lds_f32(smem, rec + 16);
-                        lds_put_f32(smem, rec, acc + lds_f32(smem, G.y_off + 4u * (uint32_t)cg));   // channel last, ldpc.py:322
+                        lds_put_f32(smem, rec, acc + ycur[k]);                        // channel last, ldpc.py:322
                     }
                 }
             }
@@ -275,17 +277,46 @@ slot_minsum_kernel(const SlotTables tb, const DecodeArgs a)
         }
 
         // ================= outputs
-        for (int x = tid; x < F * nbytes; x += NT) {
-            const int ff = x / nbytes;
-            const int qb = x - ff * nbytes;
-            const int64_t fr = fb * F + ff;
-            if (fr < a.n_frames) {
-                uint32_t byte = 0;
+        if ((n & 7) == 0) {
+            // frames are whole bytes long, so the packed decisions of the block are one contiguous
+            // bit string: 64 columns per wave and step, lane j < 8 stores byte j of the wave's word
+            const int64_t left = a.n_frames - fb * F;
+            const int vbits = (int)(left < F ? left : F) * n;
+            const int lane = tid & 63;
+            const int w0 = (int)opaque((uint32_t)(tid & ~63));
 #pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    if (qb * 8 + k < n) byte |= (uint32_t)(lds_f32(smem, (uint32_t)(ff * n + qb * 8 + k) * CB) > 0.0f) << k;
-                if (a.hard) a.hard[fr * nbytes + qb] = (uint8_t)byte;
-                if (byte) atomicAdd(&ones_cnt[ff], (int)__popc(byte));
+            for (int k = 0; k < YMAX; ++k) {
+                const int c0 = k * NT + w0;
+                if (c0 < vbits) {                                   // uniform per wave
+                    const int cg = c0 + lane;
+                    const bool one = cg < vbits && lds_f32(smem, (uint32_t)cg * CB) > 0.0f;
+                    const unsigned long long bits = __ballot(one);
+                    if (a.hard && lane < 8 && c0 + 8 * lane < vbits)
+                        a.hard[fb * F * (int64_t)nbytes + (c0 >> 3) + lane] = (uint8_t)(bits >> (8 * lane));
+                    if (bits) {
+                        const int ff = (int)((colf >> (8 * k)) & 0xffull);
+                        const int f_lo = __builtin_amdgcn_readfirstlane(ff);
+                        const int f_hi = (c0 + 63 < vbits ? c0 + 63 : vbits - 1) / n;
+                        for (int fr = f_lo; fr <= f_hi; ++fr) {
+                            const int cnt = __popcll(bits & __ballot(ff == fr));
+                            if (cnt && lane == 0) atomicAdd(&ones_cnt[fr], cnt);
+                        }
+                    }
+                }
+            }
+        } else {
+            for (int x = tid; x < F * nbytes; x += NT) {
+                const int ff = x / nbytes;
+                const int qb = x - ff * nbytes;
+                const int64_t fr = fb * F + ff;
+                if (fr < a.n_frames) {
+                    uint32_t byte = 0;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k)
+                        if (qb * 8 + k < n) byte |= (uint32_t)(lds_f32(smem, (uint32_t)(ff * n + qb * 8 + k) * CB) > 0.0f) << k;
+                    if (a.hard) a.hard[fr * nbytes + qb] = (uint8_t)byte;
+                    if (byte) atomicAdd(&ones_cnt[ff], (int)__popc(byte));
+                }
             }
         }
         if (a.soft) {
