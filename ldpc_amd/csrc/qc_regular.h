@@ -307,10 +307,10 @@ qc_regular_kernel(const RegTables tb, const DecodeArgs a)
                 if (a.sign_mode == LDPC_SIGN_CORRECTED) S ^= (uint32_t)D & 1u;
                 const uint32_t full = D > 0 ? (0xffffffffu << (32 - D)) : 0u;
                 nw.signs = R ^ (S ? full : 0u);
-                if (a.ms_alpha != 1.0f || a.ms_beta != 0.0f) {
-                    nw.min1 = ms_correct(nw.min1, a.ms_alpha, a.ms_beta);
-                    nw.min2 = ms_correct(nw.min2, a.ms_alpha, a.ms_beta);
-                }
+                // normalised / offset min-sum; unconditional on purpose (a branch here costs the
+                // register allocator hundreds of bytes of spills); exact identity for alpha = 1, beta = 0
+                nw.min1 = ms_correct(nw.min1, a.ms_alpha, a.ms_beta);
+                nw.min2 = ms_correct(nw.min2, a.ms_alpha, a.ms_beta);
                 set_wave_prio(0);
                 lds_store_state(smem, my_state, nw);
                 if (synd != 0ull) flags[par * FPW + f] = 1;
