@@ -77,3 +77,53 @@ def test_gym_evaluation_step(fx):
     ev3 = gym_eval.CodeEvaluator(seed=11, numberOfTransmissions=12, numberOfDevices=2)
     _, stats3 = ev3.step(codes.near_earth())
     assert len(stats3.getStatsV2()[0]) == 36
+
+
+def test_hex_helpers_match_reference(fx):
+    """nibble / hex conversions of fileHandler.py:36-135 on the vectors the reference produced."""
+    from ldpc_amd import fileHandler as fh
+    digits, text = fh.binaryArraytoHex(fx['hex_bits'])
+    assert text == str(fx['hex_text'])
+    assert np.array_equal(digits, fx['hex_digits'])
+    back = fh.hexStringToBinaryArray(str(fx['hex_text']) + 'g\n')       # unknown characters add nothing
+    assert back.dtype == np.int32 and np.array_equal(back, fx['hex_back'])
+    circ = fh.hexToCirculant(str(fx['inst_hex_head'])[:128], 511)
+    assert circ.shape == (511, 511)
+    assert np.array_equal(circ[0], fx['circ_row0']) and np.array_equal(circ[:, 0], fx['circ_col0'])
+    assert fh.nibbleToHex([1, 0, 1, 1]) == 'B' and fh.nibbleToHex([0, 1, 1, 1]) == '7'
+
+
+def test_code_instance_name_and_workspace_match_reference(fx, tmp_path):
+    """saveCodeInstance (fileHandler.py:203-231): file name, returned name, keys, shapes, dtypes
+    and evaluation arrays equal what the reference wrote for the same matrix and statistics."""
+    import scipy.io
+    from ldpc_amd import codes, common, fileHandler as fh
+    H = fh.nearEarthParity()
+    hex_name, hashed = fh.codeInstanceName(H, 511)
+    assert hashlib.sha256(hex_name.encode()).hexdigest() == str(fx['inst_hex_sha256'])
+    assert hex_name[:256] == str(fx['inst_hex_head'])
+    assert hashed + '.mat' == str(fx['inst_file'])
+    stats = common.berStatistics()
+    for k in range(6):
+        stats.addEntry(3.0 + 0.2 * (k % 3), 0.5, 0.49, 0.02, 0.001 * k, 5 + k, 50, 'test')
+    returned = fh.saveCodeInstance(H, 511, 8176, evaluationData=stats, path=str(tmp_path) + '/', evaluationTime=1.5,
+                                   numberOfNonZero=int(H.sum()))
+    assert (returned == hex_name) == bool(fx['inst_returned_is_hex'])
+    assert os.listdir(tmp_path) == [str(fx['inst_file'])]
+    ws = scipy.io.loadmat(os.path.join(tmp_path, str(fx['inst_file'])))
+    keys = sorted(k for k in ws if not k.startswith('__'))
+    assert keys == list(fx['inst_keys'])
+    assert [str(ws[k].shape) for k in keys] == list(fx['inst_shapes'])
+    assert [str(ws[k].dtype) for k in keys] == list(fx['inst_dtypes'])
+    for mine, ref in (('berData', 'inst_ber'), ('snrData', 'inst_snr'), ('itrData', 'inst_itr'),
+                      ('averageSnrAxis', 'inst_avg_snr')):
+        assert np.array_equal(ws[mine], fx[ref]), mine
+    # and back: shift lists from the saved workspace
+    code, rest = fh.loadCodeInstance(os.path.join(tmp_path, str(fx['inst_file'])))
+    assert isinstance(code, codes.QCCode) and code.key() == codes.near_earth().key()
+    assert int(rest['nonZero'][0, 0]) == 32704
+    # explicit file name; circulant sizes the hex naming cannot express fail as in the reference
+    assert fh.saveCodeInstance(H, 511, 8176, path=str(tmp_path) + '/', fileName='variant_0_3') == 'variant_0_3'
+    assert os.path.exists(os.path.join(tmp_path, 'variant_0_3.mat'))
+    with pytest.raises(AssertionError):
+        fh.binaryMatrixToHexString(np.zeros((81, 162), np.int32), 81)
