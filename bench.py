@@ -78,6 +78,12 @@ def main():
                          'default so that a profile of the default command sees only identical launches)')
     args = ap.parse_args()
 
+    # stdout carries exactly one line, the JSON result: RCCL and gloo print banners straight to file
+    # descriptor 1 when a process group comes up, so descriptor 1 points at stderr until the result is ready
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -92,7 +98,10 @@ def main():
     backend = os.environ.get('LDPC_BENCH_BACKEND', 'nccl')
     n_cards = torch.cuda.device_count()
     card = local_rank % max(n_cards, 1) if backend != 'nccl' else local_rank
-    if world > 1:
+    # LDPC_BENCH_FORCE_DIST=1: initialise the process group for a single rank too (checks the RCCL
+    # path on a one-card box: python -m torch.distributed.run --nproc-per-node 1 bench.py)
+    use_dist = world > 1 or (os.environ.get('LDPC_BENCH_FORCE_DIST') == '1' and 'RANK' in os.environ)
+    if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         torch.cuda.set_device(card)
         if backend == 'nccl':
@@ -134,7 +143,7 @@ def main():
         c = torch.stack([torch.tensor(F, device=dev, dtype=torch.int64),
                          (ones != 0).sum(), ones.sum(dtype=torch.int64), iters.sum(dtype=torch.int64),
                          unc.sum(dtype=torch.int64), (conv == 0).sum()])
-        if world > 1:
+        if use_dist:
             if backend == 'nccl':
                 dist.all_reduce(c)      # the path's only exchange: error counters (RCCL)
             else:
@@ -147,7 +156,7 @@ def main():
         step()
         counters()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
@@ -159,11 +168,11 @@ def main():
         ev[k][1].record(stream)
         c = counters()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], device=dev if backend == 'nccl' else 'cpu', dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -256,8 +265,9 @@ def main():
             out['cpu_baseline'] = base
             if args.prec == 64:
                 out['cpu_gpu_iters_equal'] = bool(np.array_equal(it_cpu, iters[:m].cpu().numpy()))
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + '\n').encode())
+    if use_dist:
         dist.destroy_process_group()
 
 
