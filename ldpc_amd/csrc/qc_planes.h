@@ -130,9 +130,15 @@ planes_check_pass(unsigned char *smem, const uint32_t (&radr)[CPT * 4], int D, i
                 R = __builtin_amdgcn_alignbit(R, __float_as_uint(v), 31);   // (R << 1) | sign(v), ldpc.py:139
                 const float av = fabsf(v);                                  // ldpc.py:178
                 const bool lt = av < min1;
-                min2 = __builtin_amdgcn_fmed3f(min1, min2, av);
                 idx = lt ? (uint32_t)s : idx;
-                min1 = __builtin_amdgcn_fmed3f(min1, av, -INF);             // min(min1, av) without a canonicalising extra
+                // second minimum and minimum as bare instructions: behind the register pins below the
+                // compiler no longer knows that min1/min2 are canonical and would put a v_max x, x
+                // in front of its own med3 / min once per chunk
+                float n2, n1;
+                asm("v_med3_f32 %0, %1, %2, |%3|" : "=v"(n2) : "v"(min1), "v"(min2), "v"(v));
+                asm("v_min_f32 %0, %1, |%2|" : "=v"(n1) : "v"(min1), "v"(v));
+                min2 = n2;
+                min1 = n1;
             }
             // Pin the running state here.  Otherwise instruction selection defers the whole
             // second-minimum / argmin / syndrome chains to the end of the pass and keeps every
@@ -410,9 +416,12 @@ planes_role(unsigned char *smem, const PlanesTables &tb, const DecodeArgs &a)
     // phase timing without perturbing the steady state: clock samples are summed in
     // (scalar) registers and written once when the workgroup has finished
     unsigned long long tr[11] = {0}, tr_acc[12] = {0}, tr_last = 0;
+    unsigned long long it_acc[4] = {0}, it_t = 0;           // steady-state loop: check, barrier, variable, barrier
 #define TRACE(k) tr[k] = clock64()
+#define TRACE_IT(k) { const unsigned long long now_ = clock64(); if (k >= 0) it_acc[k < 0 ? 0 : k] += now_ - it_t; it_t = now_; }
 #else
 #define TRACE(k)
+#define TRACE_IT(k)
 #endif
     for (int64_t frame = blockIdx.x, next_frame = 0; frame < n_frames; frame = next_frame) {
         TRACE(0);
@@ -454,6 +463,7 @@ planes_role(unsigned char *smem, const PlanesTables &tb, const DecodeArgs &a)
                 if (tid == 0) flags[1] = 0;
                 if (live) variable_pass(y);
                 lds_barrier();
+                TRACE_IT(-1);
                 for (int it = 1;; ++it) {
                     const int par = it & 1;
                     if (live) {
@@ -462,7 +472,9 @@ planes_role(unsigned char *smem, const PlanesTables &tb, const DecodeArgs &a)
                             : planes_check_pass<Z, CPT, B, false>(smem, radr, D, a.sign_mode, ic, synd0, a.ms_alpha, a.ms_beta);
                         if (synd != 0ull) flags[par] = 1;
                     }
+                    TRACE_IT(0);
                     lds_barrier();
+                    TRACE_IT(1);
                     const int bad2 = __builtin_amdgcn_readfirstlane(flags[par]);   // stop test, ldpc.py:332-335
                     if (bad2 == 0 || it >= a.max_iters) {
                         my_iters = it;
@@ -471,7 +483,9 @@ planes_role(unsigned char *smem, const PlanesTables &tb, const DecodeArgs &a)
                     }
                     if (tid == 0) flags[par ^ 1] = 0;
                     if (live) variable_pass(y);
+                    TRACE_IT(2);
                     lds_barrier();
+                    TRACE_IT(3);
                 }
             }
         }
@@ -535,6 +549,9 @@ planes_role(unsigned char *smem, const PlanesTables &tb, const DecodeArgs &a)
     if (lane == 0 && a.soft)
         for (int k = 0; k < 12; ++k)
             reinterpret_cast<unsigned long long *>(a.soft)[((size_t)blockIdx.x * 16 + (tid >> 6)) * 12 + k] = tr_acc[k];
+    if (lane == 0 && a.soft)
+        for (int k = 0; k < 4; ++k)
+            reinterpret_cast<unsigned long long *>(a.soft)[(size_t)gridDim.x * 16 * 12 + ((size_t)blockIdx.x * 16 + (tid >> 6)) * 4 + k] = it_acc[k];
 #endif
 }
 

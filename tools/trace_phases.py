@@ -24,7 +24,7 @@ def main():
     eng.set_stream(stream.cuda_stream)
     F, n = args.frames, eng.n
     llr = torch.empty((F, n), dtype=torch.float32, device=dev)
-    soft = torch.zeros((256 * 16 * 12 * 2,), dtype=torch.float32, device=dev)
+    soft = torch.zeros((256 * 16 * 16 * 2,), dtype=torch.float32, device=dev)
     iters = torch.empty(F, dtype=torch.int32, device=dev)
     hard = torch.empty((F, eng.nbytes), dtype=torch.uint8, device=dev)
     conv = torch.empty(F, dtype=torch.uint8, device=dev)
@@ -40,13 +40,21 @@ def main():
             e1.record(stream)
             torch.cuda.synchronize()
         print(f'budget {b}: kernel {e0.elapsed_time(e1):.3f} ms = {e0.elapsed_time(e1) * 1e3 / F * 256:.2f} us per frame per CU')
-        t = soft.cpu().numpy().view(np.uint64).reshape(256, 16, 12).astype(np.float64)
+        raw = soft.cpu().numpy().view(np.uint64)
+        t = raw[:256 * 16 * 12].reshape(256, 16, 12).astype(np.float64)
+        inner = raw[256 * 16 * 12:].reshape(256, 16, 4).astype(np.float64)
+        iters_total = float(iters.sum().item())
         per = t[:, :, :11] / t[:, :, 11:12]                 # mean cycles per frame, [workgroup, wave, phase]
         m = per.mean(axis=0)
         print('  mean cycles per frame and phase (rows: waves 0, 4, 8, 12, 15; last column: sum)')
         print('        ' + ' '.join(f'{n[:10]:>10s}' for n in names))
         for w in (0, 4, 8, 12, 15):
             print(f'  w{w:<4d} ' + ' '.join(f'{v:10.0f}' for v in m[w]) + f' {m[w].sum():10.0f}')
+        # steady-state loop, cycles per frame-iteration: every workgroup's sum over its frames / iterations it ran
+        per_it = inner.sum(axis=0) / iters_total
+        print('  steady-state loop, mean cycles per iteration (check pass, barrier, variable pass, barrier)')
+        for w in range(16):
+            print(f'  w{w:<4d} ' + ' '.join(f'{v:10.0f}' for v in per_it[w]) + f' {per_it[w].sum():10.0f}')
 
 
 if __name__ == '__main__':
