@@ -402,7 +402,13 @@ planes_role(unsigned char *smem, const PlanesTables &tb, const DecodeArgs &a)
             if (b0 + 8 <= nbytes) {
                 __builtin_memcpy(dst, &out_bits, 8);
             } else {
-                for (int k = 0; b0 + k < nbytes; ++k) dst[k] = (uint8_t)(out_bits >> (8 * k));
+                // the frame's last bytes: at most three stores (4 + 2 + 1 bytes), no loop -- the wave that
+                // owns them is the one every other wave of the workgroup waits for at the next barrier
+                const int r = nbytes - b0;
+                int k = 0;
+                if (r & 4) { const uint32_t w = (uint32_t)out_bits; __builtin_memcpy(dst, &w, 4); k = 4; }
+                if (r & 2) { const uint16_t w = (uint16_t)(out_bits >> (8 * k)); __builtin_memcpy(dst + k, &w, 2); k += 2; }
+                if (r & 1) dst[k] = (uint8_t)(out_bits >> (8 * k));
             }
         }
         if (tid == 0) {
