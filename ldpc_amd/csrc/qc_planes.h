@@ -62,8 +62,11 @@ planes_load_frame(const void *llr, int is_f64, int64_t frame_base, uint32_t firs
 #ifndef PLANES_CH
 #define PLANES_CH 4                 // edges per pipeline stage of the check pass
 #endif
+#ifndef PLANES_PRIO
+#define PLANES_PRIO 1               // 0: no priority staging in the check pass (5 % slower; kept for comparison)
+#endif
 #ifndef PLANES_VB
-#define PLANES_VB 4                 // columns per batch of the variable pass
+#define PLANES_VB 2                 // columns per batch of the variable pass (measured: 2 < 4 < 1 < 8)
 #endif
 
 struct PlanesTables {
@@ -119,7 +122,7 @@ planes_check_pass(unsigned char *smem, const uint32_t (&radr)[CPT * 4], int D, i
         // finish the pass one after the other, the last one alone with its LDS latency
         // exposed.  Dropping priority as the pass advances keeps the waves level
         // (measured: 11 % off the iteration time; finer steps than one per 8 edges were slower).
-        if (k * CH % 8 == 0) set_wave_prio(3 - (k * CH / 8) * 3 / (NS / 8 - 1));
+        if (PLANES_PRIO && k * CH % 8 == 0) set_wave_prio(3 - (k * CH / 8) * 3 / (NS / 8 - 1));
         const int cb = k & 1;
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
@@ -229,7 +232,7 @@ planes_check_pass_spa(unsigned char *smem, const uint32_t (&radr)[CPT * 4], int 
         }
         __builtin_amdgcn_sched_barrier(0);
         if (k < 0) continue;
-        if (k * CH % 8 == 0) set_wave_prio(3 - (k * CH / 8) * 3 / (NS / 8 - 1));
+        if (PLANES_PRIO && k * CH % 8 == 0) set_wave_prio(3 - (k * CH / 8) * 3 / (NS / 8 - 1));
         const int cb = k & 1;
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
