@@ -39,6 +39,18 @@ template <typename T> struct StateRaw;
 template <> struct StateRaw<float> { uint4 v; };
 template <> struct StateRaw<double> { double2 mm; uint2 mt; };
 
+// LDS byte address of a pointer into the workgroup's shared memory, and typed access by such an
+// address (lets a base offset be folded into an address computed by hand)
+__device__ __forceinline__ uint32_t lds_address(const unsigned char *p)
+{
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) unsigned char *)p;
+}
+template <typename V>
+__device__ __forceinline__ const V &lds_ref(uint32_t abs_addr)
+{
+    return *(const __attribute__((address_space(3))) V *)(uintptr_t)abs_addr;
+}
+
 __device__ __forceinline__ void lds_store_state(unsigned char *smem, uint32_t addr, const RowStateRegs<float> &s)
 {
     *reinterpret_cast<uint4 *>(smem + addr) =
@@ -57,6 +69,15 @@ __device__ __forceinline__ void lds_load_state(const unsigned char *smem, uint32
 {
     r.mm = *reinterpret_cast<const double2 *>(smem + addr);
     r.mt = *reinterpret_cast<const uint2 *>(smem + addr + 16);
+}
+__device__ __forceinline__ void lds_load_state_abs(uint32_t abs_addr, StateRaw<float> &r)
+{
+    r.v = lds_ref<uint4>(abs_addr);
+}
+__device__ __forceinline__ void lds_load_state_abs(uint32_t abs_addr, StateRaw<double> &r)
+{
+    r.mm = lds_ref<double2>(abs_addr);
+    r.mt = lds_ref<uint2>(abs_addr + 16);
 }
 // message of a row along the edge with slot number `slot` whose sign sits `rank` bits below the top.
 // Magnitudes are never negative, so OR-ing the sign bit in is the multiplication by +-1.
@@ -86,6 +107,22 @@ __device__ __forceinline__ uint32_t opaque(uint32_t x)
 {
     asm volatile("" : "+v"(x));
     return x;
+}
+
+// Half `hi` of a packed address pair plus `rel`, as ONE instruction that the optimiser can neither
+// split nor hoist out of the iteration loop (hoisted, the unpacked addresses would take twice the
+// registers the packing saves; laundering the pair instead costs a register copy per use).
+template <int HI>
+__device__ __forceinline__ uint32_t unpack_addr(uint32_t pk, uint32_t rel)
+{
+    uint32_t r;
+    if (HI)
+        asm volatile("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1"
+                     : "=v"(r) : "s"(rel), "v"(pk));
+    else
+        asm volatile("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0"
+                     : "=v"(r) : "s"(rel), "v"(pk));
+    return r;
 }
 
 // s_setprio with a value that is constant only after unrolling
@@ -129,6 +166,8 @@ qc_regular_kernel(const RegTables tb, const DecodeArgs a)
     const uint32_t post_off = (uint32_t)slots * SB;
     const uint32_t flag_off = post_off + (uint32_t)((((size_t)FPW * n * sizeof(T)) + 15) & ~(size_t)15);
     const uint32_t post_rel = sizeof(T) == 8 ? post_off : 0u;   // added when a packed posterior address is used
+    const uint32_t lds0 = lds_address(smem);                    // LDS address of the workgroup's dynamic shared memory
+    const uint32_t post_abs = post_rel + lds0;
     int *flags = reinterpret_cast<int *>(smem + flag_off);   // [2][FPW] "syndrome non-zero"
     int *ones_cnt = flags + 2 * FPW;                          // [FPW]
     int *claim_word = flags + 3 * FPW;                        // [1] block of frames decoded after the next one
@@ -280,8 +319,8 @@ qc_regular_kernel(const RegTables tb, const DecodeArgs a)
                     for (int u = 0; u < CH; ++u) {
                         const int s = c0 + u;
                         if (s < NS && (!HOLES || ((rmask >> (s / W)) & 1u))) {
-                            const uint32_t ad = ((s & 1) ? (opaque(rpk[s / 2]) >> 16) : (opaque(rpk[s / 2]) & 0xffffu)) + post_rel;
-                            p[u] = *reinterpret_cast<const T *>(smem + ad);
+                            const uint32_t ad = (s & 1) ? unpack_addr<1>(rpk[s / 2], post_abs) : unpack_addr<0>(rpk[s / 2], post_abs);
+                            p[u] = lds_ref<T>(ad);
                         }
                     }
 #pragma unroll
@@ -350,8 +389,8 @@ qc_regular_kernel(const RegTables tb, const DecodeArgs a)
                                 const int q = q0 + dq, fl = (q * MB + b) * W + k;
                                 const int j = g + q * MB;
                                 if (q < CPT && (!HOLES || ((cmask[b] >> j) & 1u))) {
-                                    const uint32_t ad = (fl & 1) ? (opaque(cpk[fl / 2]) >> 16) : (opaque(cpk[fl / 2]) & 0xffffu);
-                                    lds_load_state(smem, ad, st[dq][b][k]);
+                                    const uint32_t ad = (fl & 1) ? unpack_addr<1>(cpk[fl / 2], lds0) : unpack_addr<0>(cpk[fl / 2], lds0);
+                                    lds_load_state_abs(ad, st[dq][b][k]);
                                 }
                             }
 #pragma unroll
