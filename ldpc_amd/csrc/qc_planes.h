@@ -194,12 +194,18 @@ planes_check_pass(unsigned char *smem, const uint32_t (&radr)[CPT * 4], int D, i
 //   x <  2        ln((1 + t) / (1 - t)), with 1 - t from its series below 1/16 (cancellation)
 __device__ __forceinline__ float planes_phi(float x)
 {
-    const float t = __expf(-x);
+    // explicit fused multiply-adds: the file is compiled without contraction (the min-sum kernels'
+    // rounding order is part of their contract), which would otherwise split every polynomial step in two
+    // Bare v_exp_f32 / v_log_f32 / v_rcp_f32 (1 ulp each): __expf, __logf and __frcp_rn expand to range
+    // checks, rescaling for denormals and a full division sequence, none of which this range needs
+    // (e^-80 = 1.8e-35 is a normal number; the logarithm's argument is >= 1).
+    const float t = __builtin_amdgcn_exp2f(x * -1.4426950408889634f);
     const float t2 = t * t;
-    const float series = (t + t) * (1.0f + t2 * (0.33333334f + t2 * (0.2f + t2 * 0.14285715f)));
-    const float om_small = x * (1.0f - x * (0.5f - x * (0.16666667f - x * (0.041666668f - x * 0.008333334f))));
+    const float series = (t + t) * __fmaf_rn(t2, __fmaf_rn(t2, __fmaf_rn(t2, 0.14285715f, 0.2f), 0.33333334f), 1.0f);
+    const float om_small = x * __fmaf_rn(-x, __fmaf_rn(-x, __fmaf_rn(-x, __fmaf_rn(-x, 0.008333334f, 0.041666668f),
+                                                                     0.16666667f), 0.5f), 1.0f);
     const float om = x < 0.0625f ? om_small : 1.0f - t;
-    const float lg = __logf((1.0f + t) * __frcp_rn(om));
+    const float lg = __builtin_amdgcn_logf((1.0f + t) * __builtin_amdgcn_rcpf(om)) * 0.6931471805599453f;
     return x >= 2.0f ? series : lg;
 }
 

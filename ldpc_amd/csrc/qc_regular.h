@@ -45,8 +45,11 @@ __device__ __forceinline__ uint32_t lds_address(const unsigned char *p)
 {
     return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) unsigned char *)p;
 }
-template <typename V>
-__device__ __forceinline__ const V &lds_ref(uint32_t abs_addr)
+typedef uint32_t lds_u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t lds_u32x2 __attribute__((ext_vector_type(2)));
+typedef double lds_f64x2 __attribute__((ext_vector_type(2)));
+template <typename V>          // V: a scalar or one of the native vector types above
+__device__ __forceinline__ V lds_load(uint32_t abs_addr)
 {
     return *(const __attribute__((address_space(3))) V *)(uintptr_t)abs_addr;
 }
@@ -72,12 +75,15 @@ __device__ __forceinline__ void lds_load_state(const unsigned char *smem, uint32
 }
 __device__ __forceinline__ void lds_load_state_abs(uint32_t abs_addr, StateRaw<float> &r)
 {
-    r.v = lds_ref<uint4>(abs_addr);
+    const lds_u32x4 v = lds_load<lds_u32x4>(abs_addr);
+    r.v = make_uint4(v.x, v.y, v.z, v.w);
 }
 __device__ __forceinline__ void lds_load_state_abs(uint32_t abs_addr, StateRaw<double> &r)
 {
-    r.mm = lds_ref<double2>(abs_addr);
-    r.mt = lds_ref<uint2>(abs_addr + 16);
+    const lds_f64x2 mm = lds_load<lds_f64x2>(abs_addr);
+    const lds_u32x2 mt = lds_load<lds_u32x2>(abs_addr + 16);
+    r.mm = make_double2(mm.x, mm.y);
+    r.mt = make_uint2(mt.x, mt.y);
 }
 // message of a row along the edge with slot number `slot` whose sign sits `rank` bits below the top.
 // Magnitudes are never negative, so OR-ing the sign bit in is the multiplication by +-1.
@@ -320,7 +326,7 @@ qc_regular_kernel(const RegTables tb, const DecodeArgs a)
                         const int s = c0 + u;
                         if (s < NS && (!HOLES || ((rmask >> (s / W)) & 1u))) {
                             const uint32_t ad = (s & 1) ? unpack_addr<1>(rpk[s / 2], post_abs) : unpack_addr<0>(rpk[s / 2], post_abs);
-                            p[u] = lds_ref<T>(ad);
+                            p[u] = lds_load<T>(ad);
                         }
                     }
 #pragma unroll

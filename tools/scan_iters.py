@@ -15,6 +15,7 @@ def main():
     ap.add_argument('--snr', type=float, default=1.0)
     ap.add_argument('--code', default='nearEarth')
     ap.add_argument('--budgets', default='0,1,2,4,8,16')
+    ap.add_argument('--algo', default='minsum', choices=['minsum', 'spa'])
     ap.add_argument('--no-hard', action='store_true')
     ap.add_argument('--no-ones', action='store_true')
     args = ap.parse_args()
@@ -36,14 +37,16 @@ def main():
     conv = torch.empty(F, dtype=torch.uint8, device=dev)
     ones = torch.empty(F, dtype=torch.int32, device=dev)
     eng.channel_awgn_device(llr, F, args.snr, seed=1)
-    print('launch', eng.launch_info(prec=args.prec))
+    algo = ldpc_amd.ALGO_SUMPRODUCT if args.algo == 'spa' else ldpc_amd.ALGO_MINSUM
+    scale = 4.0 * 10 ** (args.snr / 10) if args.algo == 'spa' else 1.0      # sum-product takes 2y/sigma^2
+    print('launch', eng.launch_info(algo=algo, prec=args.prec))
     res = []
     for b in [int(x) for x in args.budgets.split(',')]:
         ts = []
         for rep in range(3):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(stream)
-            eng.decode_device(llr, F, b, prec=args.prec, d_hard=None if args.no_hard else hard, d_iters=iters, d_conv=conv,
+            eng.decode_device(llr, F, b, prec=args.prec, algo=algo, llr_scale=scale, d_hard=None if args.no_hard else hard, d_iters=iters, d_conv=conv,
                               d_ones=None if args.no_ones else ones)
             e1.record(stream)
             torch.cuda.synchronize()
