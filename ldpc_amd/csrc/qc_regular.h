@@ -26,8 +26,10 @@ struct RegTables {
 template <typename T> struct RegState;
 // float: {min1, min2, sign bits (left aligned, pre-multiplied by the row's sign product), argmin slot}
 template <> struct RegState<float> { enum { BYTES = 16 }; };
-// double: {min1, min2} {sign bits, argmin slot, pad, pad}
-template <> struct RegState<double> { enum { BYTES = 32 }; };
+// double: {sign bits, argmin slot} {min1} {min2}: the variable pass reads the first 8 bytes, then only the
+// magnitude it needs (16 bytes per edge instead of 24; the pass is bound by LDS traffic).  A stride of
+// 24 bytes also keeps the 8-byte reads of 16 consecutive rows on distinct banks.
+template <> struct RegState<double> { enum { BYTES = 24 }; };
 
 __device__ __forceinline__ uint32_t hi_bits(float v) { return __float_as_uint(v); }
 __device__ __forceinline__ uint32_t hi_bits(double v) { return (uint32_t)__double2hiint(v); }
@@ -37,7 +39,7 @@ template <typename T> struct RowStateRegs { T min1, min2; uint32_t signs, idx; }
 // LDS image of a row state as it is read by the variable pass
 template <typename T> struct StateRaw;
 template <> struct StateRaw<float> { uint4 v; };
-template <> struct StateRaw<double> { double2 mm; uint2 mt; };
+template <> struct StateRaw<double> { uint2 mt; double mag; };
 
 // LDS byte address of a pointer into the workgroup's shared memory, and typed access by such an
 // address (lets a base offset be folded into an address computed by hand)
@@ -61,29 +63,26 @@ __device__ __forceinline__ void lds_store_state(unsigned char *smem, uint32_t ad
 }
 __device__ __forceinline__ void lds_store_state(unsigned char *smem, uint32_t addr, const RowStateRegs<double> &s)
 {
-    *reinterpret_cast<double2 *>(smem + addr) = make_double2(s.min1, s.min2);
-    *reinterpret_cast<uint2 *>(smem + addr + 16) = make_uint2(s.signs, s.idx);
-}
-__device__ __forceinline__ void lds_load_state(const unsigned char *smem, uint32_t addr, StateRaw<float> &r)
-{
-    r.v = *reinterpret_cast<const uint4 *>(smem + addr);
-}
-__device__ __forceinline__ void lds_load_state(const unsigned char *smem, uint32_t addr, StateRaw<double> &r)
-{
-    r.mm = *reinterpret_cast<const double2 *>(smem + addr);
-    r.mt = *reinterpret_cast<const uint2 *>(smem + addr + 16);
+    *reinterpret_cast<uint2 *>(smem + addr) = make_uint2(s.signs, s.idx);
+    *reinterpret_cast<double *>(smem + addr + 8) = s.min1;
+    *reinterpret_cast<double *>(smem + addr + 16) = s.min2;
 }
 __device__ __forceinline__ void lds_load_state_abs(uint32_t abs_addr, StateRaw<float> &r)
 {
     const lds_u32x4 v = lds_load<lds_u32x4>(abs_addr);
     r.v = make_uint4(v.x, v.y, v.z, v.w);
 }
+// double, first step: sign bits and argmin slot of the row
 __device__ __forceinline__ void lds_load_state_abs(uint32_t abs_addr, StateRaw<double> &r)
 {
-    const lds_f64x2 mm = lds_load<lds_f64x2>(abs_addr);
-    const lds_u32x2 mt = lds_load<lds_u32x2>(abs_addr + 16);
-    r.mm = make_double2(mm.x, mm.y);
+    const lds_u32x2 mt = lds_load<lds_u32x2>(abs_addr);
     r.mt = make_uint2(mt.x, mt.y);
+}
+// second step: the magnitude the row sent along the edge with slot number `slot` (min2 to its argmin edge)
+__device__ __forceinline__ void lds_load_magnitude(uint32_t, StateRaw<float> &, uint32_t) {}
+__device__ __forceinline__ void lds_load_magnitude(uint32_t abs_addr, StateRaw<double> &r, uint32_t slot)
+{
+    r.mag = lds_load<double>(abs_addr + (r.mt.y == slot ? 16u : 8u));
 }
 // message of a row along the edge with slot number `slot` whose sign sits `rank` bits below the top.
 // Magnitudes are never negative, so OR-ing the sign bit in is the multiplication by +-1.
@@ -92,10 +91,9 @@ __device__ __forceinline__ float rebuild_msg(const StateRaw<float> &r, uint32_t 
     const uint32_t mag = (r.v.w == slot) ? r.v.y : r.v.x;
     return __uint_as_float(mag | ((r.v.z << rank) & 0x80000000u));
 }
-__device__ __forceinline__ double rebuild_msg(const StateRaw<double> &r, uint32_t slot, uint32_t rank)
+__device__ __forceinline__ double rebuild_msg(const StateRaw<double> &r, uint32_t, uint32_t rank)
 {
-    const double mag = (r.mt.y == slot) ? r.mm.y : r.mm.x;
-    return __hiloint2double(__double2hiint(mag) | (int)((r.mt.x << rank) & 0x80000000u), __double2loint(mag));
+    return __hiloint2double(__double2hiint(r.mag) | (int)((r.mt.x << rank) & 0x80000000u), __double2loint(r.mag));
 }
 // previous message of my own row: non-negative magnitude, sign = bit 31 of signword
 __device__ __forceinline__ float with_top_sign(float mag, uint32_t signword)
@@ -386,6 +384,7 @@ qc_regular_kernel(const RegTables tb, const DecodeArgs a)
                 for (int q0 = 0; q0 < CPT; q0 += VQ) {
                     set_wave_prio(3 - q0 * 3 / (CPT > 2 ? CPT - 2 : 1));
                     StateRaw<T> st[VQ][MB][W];
+                    uint32_t sad[VQ][MB][W];
 #pragma unroll
                     for (int dq = 0; dq < VQ; ++dq)
 #pragma unroll
@@ -396,9 +395,22 @@ qc_regular_kernel(const RegTables tb, const DecodeArgs a)
                                 const int j = g + q * MB;
                                 if (q < CPT && (!HOLES || ((cmask[b] >> j) & 1u))) {
                                     const uint32_t ad = (fl & 1) ? unpack_addr<1>(cpk[fl / 2], lds0) : unpack_addr<0>(cpk[fl / 2], lds0);
+                                    sad[dq][b][k] = ad;
                                     lds_load_state_abs(ad, st[dq][b][k]);
                                 }
                             }
+                    if (sizeof(T) == 8) {
+#pragma unroll
+                        for (int dq = 0; dq < VQ; ++dq)
+#pragma unroll
+                            for (int b = 0; b < MB; ++b)
+#pragma unroll
+                                for (int k = 0; k < W; ++k) {
+                                    const int q = q0 + dq, j = g + q * MB;
+                                    if (q < CPT && (!HOLES || ((cmask[b] >> j) & 1u)))
+                                        lds_load_magnitude(sad[dq][b][k], st[dq][b][k], (uint32_t)(j * W + k));
+                                }
+                    }
 #pragma unroll
                     for (int dq = 0; dq < VQ; ++dq) {
                         const int q = q0 + dq;
