@@ -157,10 +157,11 @@ template <typename T, int MB, int W, int CPT, int FPW, bool HOLES>
 __global__ void __launch_bounds__(1024)
 qc_regular_kernel(const RegTables tb, const DecodeArgs a)
 {
-    // chunk of the check pass / columns per batch of the variable pass: halved for double,
-    // whose values take two registers each (the larger batches spill)
+    // chunk of the check pass / columns per batch of the variable pass: halved for double, whose
+    // values take two registers each (measured, float64: two columns per batch +3.4 % on the 2-row
+    // NearEarth shape in spite of 100 bytes of spills, -12 % on the 4-row 802.11n shape)
     enum { NB = CPT * MB, NS = NB * W, SB = RegState<T>::BYTES, NC = CPT * MB * W,
-           CH = sizeof(T) == 8 ? 8 : 16, VQ = sizeof(T) == 8 ? 1 : 2 };
+           CH = sizeof(T) == 8 ? 8 : 16, VQ = sizeof(T) == 8 ? (MB == 2 ? 2 : 1) : 2 };
     static_assert(NS <= 32, "sign bits of a row must fit one register");
     static_assert(NS % 2 == 0 && NC % 2 == 0, "addresses are packed in pairs");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
