@@ -247,16 +247,34 @@ qc_minsum_kernel(const QcTables tb, const DecodeArgs a)
         const bool valid = frame < a.n_frames;
 
         // ---- load channel values; posterior := channel (decoderSet, ldpc.py:270-274)
+        // All loads of the frame are issued before the first one is waited for (one branch on the
+        // input type around the whole batch, not one per value: that serialised them).
         T y[CPT];
+        {
+            const bool take = live && valid;
+            const int64_t base = take ? frame * n + i : 0;
+            if (a.llr_f64) {
+                const double *src = reinterpret_cast<const double *>(a.llr) + base;
 #pragma unroll
-        for (int q = 0; q < CPT; ++q) {
-            const int j = g + q * mb;
-            y[q] = T(0);
-            if (j < nb && live && valid) {
+                for (int q = 0; q < CPT; ++q) {
+                    const int j = g + q * mb;
+                    y[q] = (take && j < nb) ? T(src[(int64_t)j * Z]) : T(0);
+                }
+            } else {
+                const float *src = reinterpret_cast<const float *>(a.llr) + base;
+#pragma unroll
+                for (int q = 0; q < CPT; ++q) {
+                    const int j = g + q * mb;
+                    y[q] = (take && j < nb) ? T(src[(int64_t)j * Z]) : T(0);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < CPT; ++q) {
+                const int j = g + q * mb;
                 // "+ 0" turns a -0.0 input into +0.0: no effect on any comparison or sum
                 // below, and it keeps "sign bit set" equivalent to "< 0" for every message.
-                y[q] = load_llr<T>(a.llr, a.llr_f64, frame * n + j * Z + i) * T(a.llr_scale) + T(0);
-                post[fbase + j * Z + i] = y[q];
+                y[q] = y[q] * T(a.llr_scale) + T(0);
+                if (take && j < nb) post[fbase + j * Z + i] = y[q];
             }
         }
         if (tid < 3 * FPW) flags[tid] = 0;
