@@ -61,12 +61,19 @@ static int fail(int code, const char *fmt, ...)
 // ---------------------------------------------------------------- device tables
 struct QcTables {
     int Z, Zp, mb, nb, m, n;
+    int n_ent, n_grp;        // entries of row_ent (= of col_ent) and of col_grp
     const int32_t *row_ptr;  // [mb+1] entry ranges of each block-row
     const int2 *row_ent;     // {j*Z, s}: row i has an edge to column j*Z + (i+s) mod Z
     const int32_t *col_ptr;  // [nb+1] group ranges of each block-column
     const int4 *col_grp;     // {b, w, first entry, -}: one non-empty block (b, j), ascending b
     const int2 *col_ent;     // {s, e}: shift and edge number inside row list of b; s descending
 };
+
+// LDS copy of the tables: col_grp | row_ent | col_ent | row_ptr | col_ptr (16-byte items first)
+__host__ __device__ inline size_t qc_table_bytes(const QcTables &tb)
+{
+    return (size_t)tb.n_grp * 16 + (size_t)tb.n_ent * 16 + (((size_t)(tb.mb + 1 + tb.nb + 1) * 4 + 15) & ~(size_t)15);
+}
 
 struct CsrTables {
     int m, n, E;
@@ -215,6 +222,19 @@ qc_minsum_kernel(const QcTables tb, const DecodeArgs a)
     off += (size_t)slots * sizeof(Meta);
     int *flags = reinterpret_cast<int *>(smem + off);   // [2][FPW] "syndrome non-zero"
     int *ones_cnt = flags + 2 * FPW;                    // [FPW]
+    off = (off + 3 * FPW * sizeof(int) + 15) & ~(size_t)15;
+    // The tables live in LDS for the whole launch.  Read from global memory they cost a full
+    // (vector) load latency per edge: their addresses are uniform, but the compiler cannot prove it.
+    int4 *l_col_grp = reinterpret_cast<int4 *>(smem + off);
+    int2 *l_row_ent = reinterpret_cast<int2 *>(l_col_grp + tb.n_grp);
+    int2 *l_col_ent = l_row_ent + tb.n_ent;
+    int *l_row_ptr = reinterpret_cast<int *>(l_col_ent + tb.n_ent);
+    int *l_col_ptr = l_row_ptr + (mb + 1);
+    for (int x = threadIdx.x; x < tb.n_grp; x += blockDim.x) l_col_grp[x] = tb.col_grp[x];
+    for (int x = threadIdx.x; x < tb.n_ent; x += blockDim.x) { l_row_ent[x] = tb.row_ent[x]; l_col_ent[x] = tb.col_ent[x]; }
+    for (int x = threadIdx.x; x <= mb; x += blockDim.x) l_row_ptr[x] = tb.row_ptr[x];
+    for (int x = threadIdx.x; x <= nb; x += blockDim.x) l_col_ptr[x] = tb.col_ptr[x];
+    __syncthreads();
 
     const int tid = threadIdx.x;
     const int grp = __builtin_amdgcn_readfirstlane(tid / Zp);
@@ -224,8 +244,8 @@ qc_minsum_kernel(const QcTables tb, const DecodeArgs a)
     const bool live = i < Z;
     const int fbase = f * n;         // start of this frame's posteriors in LDS
     const int slot = grp * Zp + i;   // this row's slot in mins/meta
-    const int re0 = tb.row_ptr[g];
-    const int deg = tb.row_ptr[g + 1] - re0;
+    const int re0 = __builtin_amdgcn_readfirstlane(l_row_ptr[g]);
+    const int deg = __builtin_amdgcn_readfirstlane(l_row_ptr[g + 1]) - re0;
     const int nbytes = (n + 7) >> 3;
     const T INF = t_inf(T(0));
 
@@ -303,7 +323,7 @@ qc_minsum_kernel(const QcTables tb, const DecodeArgs a)
                 unsigned long long synd = 0;
 #pragma unroll 4
                 for (int e = 0; e < deg; ++e) {
-                    const int2 ent = tb.row_ent[re0 + e];
+                    const int2 ent = l_row_ent[re0 + e];
                     uint32_t c = (uint32_t)(i + ent.y);
                     c = min(c, c - (uint32_t)Z);                 // (i + s) mod Z
                     const T p = post[fbase + ent.x + (int)c];
@@ -360,11 +380,11 @@ qc_minsum_kernel(const QcTables tb, const DecodeArgs a)
                     const int j = g + q * mb;
                     if (j < nb) {
                         T acc = T(0);
-                        const int g0 = tb.col_ptr[j], g1 = tb.col_ptr[j + 1];
+                        const int g0 = __builtin_amdgcn_readfirstlane(l_col_ptr[j]), g1 = __builtin_amdgcn_readfirstlane(l_col_ptr[j + 1]);
                         for (int gi = g0; gi < g1; ++gi) {
-                            const int4 cg = tb.col_grp[gi];
+                            const int4 cg = l_col_grp[gi];
                             const int rbase = (f * mb + cg.x) * Zp;
-                            const int2 *ent = tb.col_ent + cg.z;
+                            const int2 *ent = l_col_ent + cg.z;
                             if (cg.y == 1) {
                                 const int2 en = ent[0];
                                 uint32_t r = (uint32_t)(i - en.x);
@@ -1108,6 +1128,7 @@ extern "C" int ldpc_create_qc(int device, int Z, int mb, int nb, const int32_t *
     h->m = mb * Z; h->n = nb * Z; h->E = blk_ptr[nblk] * Z; h->max_row_deg = max_deg;
     h->cols_per_thread = (nb + mb - 1) / mb;
     h->qc.Z = Z; h->qc.Zp = Zp; h->qc.mb = mb; h->qc.nb = nb; h->qc.m = h->m; h->qc.n = h->n;
+    h->qc.n_ent = (int)row_ent.size(); h->qc.n_grp = (int)col_grp.size();
     // regular structure?  (same weight W in {1,2} for every non-empty block, and a block
     // geometry one of the unrolled instantiations covers)
     {
@@ -1266,6 +1287,8 @@ static size_t qc_lds_bytes(const QcTables &tb)
     b += slots * sizeof(typename Vec2<T>::type);
     b += slots * sizeof(typename SignBits<S64>::Meta);
     b += 3 * FPW * sizeof(int);
+    b = (b + 15) & ~(size_t)15;
+    b += qc_table_bytes(tb);
     return (b + 15) & ~(size_t)15;
 }
 
