@@ -438,3 +438,32 @@ def test_normalised_and_offset_minsum(engines, oracle_mod, name):
     assert np.array_equal(r['iters'], iters) and np.array_equal(r['soft'], soft)
     with pytest.raises(Exception):
         eng.set_minsum_scaling(0.0, 0.0)
+
+
+@pytest.mark.parametrize('name,prec', [('nearEarth', 32), ('nearEarth', 64), ('wifi_5_6', 32), ('wifi_5_6', 64),
+                                      ('nearEarth_mut_w3', 32), ('nearEarth_mut_w7', 32), ('nearEarth_zero_1_3', 32),
+                                      ('rand_24_48', 32)])
+def test_erasures_and_exact_zeros(engines, oracle_mod, name, prec):
+    """Channel values that are exactly +0.0 / -0.0 (erased or punctured positions) scattered over
+    noisy frames: the slicer decides 0 for them (bit = x > 0, ldpc.py:47), their posteriors can stay
+    exactly zero for several iterations, and every kernel has to agree with the oracle bit for bit
+    (hard decisions, iteration counts, status, soft values)."""
+    qc, H = build_code(name)
+    n = H.shape[1]
+    prng = np.random.RandomState(97)
+    Y = make_llrs(4242, 3.6 if name.startswith('nearEarth') else 5.0, n, 24)
+    for f in range(Y.shape[0]):
+        k = min([0, 1, 8, 40, 200, n // 8][f % 6], n // 2)
+        pos = prng.choice(n, k, replace=False)
+        Y[f, pos] = np.where(prng.rand(k) < 0.5, 0.0, -0.0).astype(np.float32)
+    Y[3, :] = 0.0                                     # nothing received at all: syndrome 0, stops at once
+    dt = np.float64 if prec == 64 else np.float32
+    orc = oracle_mod.Oracle(H)
+    sign_mode = 0 if name.startswith('nearEarth') and 'mut' not in name else 1
+    hard, iters, conv, soft = orc.minsum(Y.astype(dt), 50, prec=prec, sign_mode=sign_mode, threads=8)
+    r = engines(name).decode(Y, 50, prec=prec, sign_mode=sign_mode, want_soft=True)
+    assert np.array_equal(r['iters'], iters), (r['iters'], iters)
+    assert np.array_equal(r['converged'], conv)
+    assert np.array_equal(r['hard'], hard)
+    assert np.array_equal(r['soft'], soft)
+    assert iters[3] == 0 and conv[3] == 1 and iters.max() >= 1
