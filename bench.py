@@ -200,7 +200,7 @@ def main():
                 traffic, onchip = None, None
         kernel = 'qc_planes_kernel<511, 8, false>' if args.prec == 32 else 'qc_regular_kernel<double, 2, 2, 8, 1, false>'
         if spa:
-            kernel = 'csr_spa_kernel<float>' if args.prec == 32 else 'csr_spa_kernel<double>'
+            kernel = 'qc_planes_kernel<511, 8, true>' if args.prec == 32 else 'csr_spa_kernel<double>'
             traffic, onchip = None, None
         # on-chip roofline of the float32 min-sum kernel: LDS bytes it must move per frame-iteration
         # (16 B per edge + 4 B per column + 8 B per row) against 256 CUs x 128 B/clk x 2.4 GHz
