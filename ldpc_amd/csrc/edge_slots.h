@@ -172,9 +172,14 @@ slot_minsum_kernel(const SlotTables tb, const DecodeArgs a)
                         R = __builtin_amdgcn_alignbit(R, __float_as_uint(v), 31);   // (R << 1) | sign(v), ldpc.py:139
                         const float av = fabsf(v);                                  // ldpc.py:178
                         const bool lt = av < min1;
-                        min2 = __builtin_amdgcn_fmed3f(min1, min2, av);
                         idx = lt ? (uint32_t)s : idx;
-                        min1 = __builtin_amdgcn_fmed3f(min1, av, -INF);
+                        // bare instructions: behind the register pin below the compiler would
+                        // re-canonicalise min1 (v_max x, x) in front of its own med3 / min
+                        float n2, n1;
+                        asm("v_med3_f32 %0, %1, %2, |%3|" : "=v"(n2) : "v"(min1), "v"(min2), "v"(v));
+                        asm("v_min_f32 %0, %1, |%2|" : "=v"(n1) : "v"(min1), "v"(v));
+                        min2 = n2;
+                        min1 = n1;
                     }
                     asm volatile("" : "+v"(min1), "+v"(min2), "+v"(idx), "+v"(R), "+s"(synd));
                     __builtin_amdgcn_sched_barrier(0);
