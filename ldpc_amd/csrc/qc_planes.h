@@ -84,6 +84,31 @@ struct PlanesGeom {
            LDS_BYTES = (DUMMY_OFF + CB + 15) / 16 * 16 };
 };
 
+#ifndef PLANES_PRECHECK_T
+#define PLANES_PRECHECK_T 32        // see planes_syndrome_only; 0 = never
+#endif
+
+// Only the parity of a row's hard decisions (slicer + isCodeword, ldpc.py:47, 249-268).  A frame's
+// last check pass finds every parity satisfied and all its other work is thrown away; when the pass
+// before left no more than PLANES_PRECHECK_T rows unsatisfied, this much cheaper pass is run first
+// and the full one only if it still finds a failing row.  Same stop decision, same iteration count.
+template <int Z, int CPT>
+__device__ __forceinline__ unsigned long long
+planes_syndrome_only(const unsigned char *smem, const uint32_t (&radr)[CPT * 4], unsigned long long synd0)
+{
+    enum { NS = CPT * 4, CHS = 8 };
+    unsigned long long synd = synd0;
+#pragma unroll
+    for (int s0 = 0; s0 < NS; s0 += CHS) {
+        float p[CHS];
+#pragma unroll
+        for (int u = 0; u < CHS; ++u) p[u] = lds_f32(smem, radr[s0 + u]);
+#pragma unroll
+        for (int u = 0; u < CHS; ++u) synd ^= __ballot(p[u] > 0.0f);
+    }
+    return synd;
+}
+
 // Check pass of one row of block-row B.  FIRST: the row's previous messages are all +0
 // (fresh decoder, checkNode.__init__ ldpc.py:121) and are not read.  Returns the lanes
 // whose parity check on the current hard decisions fails.
@@ -460,7 +485,8 @@ planes_role(unsigned char *smem, const PlanesTables &tb, const DecodeArgs &a)
                 const unsigned long long synd = SPA
                     ? planes_check_pass_spa<Z, CPT, B, true>(smem, radr, D, a.sign_mode, synd0)
                     : planes_check_pass<Z, CPT, B, true>(smem, radr, D, a.sign_mode, ic, synd0, a.ms_alpha, a.ms_beta);
-                if (synd != 0ull) flags[0] = 1;
+                // flags[parity]: number of rows whose check fails (bit 20: raised by the syndrome-only pass)
+                if (synd != 0ull && lane == 0) atomicAdd(&flags[0], (int)__popcll(synd));
             }
             if (a.work && tid == 0) flags[3] = claimed;
             TRACE(4);
@@ -479,18 +505,32 @@ planes_role(unsigned char *smem, const PlanesTables &tb, const DecodeArgs &a)
                 if (live) variable_pass(y);
                 lds_barrier();
                 TRACE_IT(-1);
+                int unsat = bad;                              // rows left unsatisfied by the check pass before
                 for (int it = 1;; ++it) {
                     const int par = it & 1;
+                    if (PLANES_PRECHECK_T > 0 && unsat <= PLANES_PRECHECK_T) {
+                        if (live) {
+                            const unsigned long long synd = planes_syndrome_only<Z, CPT>(smem, radr, synd0);
+                            if (synd != 0ull && lane == 0) flags[par] = 1 << 20;
+                        }
+                        lds_barrier();
+                        if (__builtin_amdgcn_readfirstlane(flags[par]) == 0) {     // stop test, ldpc.py:332-335
+                            my_iters = it;
+                            my_conv = 1;
+                            break;
+                        }
+                    }
                     if (live) {
                         const unsigned long long synd = SPA
                             ? planes_check_pass_spa<Z, CPT, B, false>(smem, radr, D, a.sign_mode, synd0)
                             : planes_check_pass<Z, CPT, B, false>(smem, radr, D, a.sign_mode, ic, synd0, a.ms_alpha, a.ms_beta);
-                        if (synd != 0ull) flags[par] = 1;
+                        if (synd != 0ull && lane == 0) atomicAdd(&flags[par], (int)__popcll(synd));
                     }
                     TRACE_IT(0);
                     lds_barrier();
                     TRACE_IT(1);
                     const int bad2 = __builtin_amdgcn_readfirstlane(flags[par]);   // stop test, ldpc.py:332-335
+                    unsat = bad2 & 0xfffff;
                     if (bad2 == 0 || it >= a.max_iters) {
                         my_iters = it;
                         my_conv = (bad2 == 0);
