@@ -17,6 +17,10 @@
 // 174-202, 295-324); results are bit-identical.
 #pragma once
 
+#ifndef REG_PRECHECK_T
+#define REG_PRECHECK_T 32            // syndrome-only pass when the pass before left at most this many rows unsatisfied; 0 = never
+#endif
+
 struct RegTables {
     int Z, Zp, nb, n;
     uint32_t row_mask[8];    // [MB] bit j set: block (b, j) is present
@@ -306,9 +310,41 @@ qc_regular_kernel(const RegTables tb, const DecodeArgs a)
             }
         }
 
+        int unsat = 0x7fffffff;                   // rows the check pass before left unsatisfied (one frame per workgroup)
         for (int it = 0;; ++it) {
             const bool active = (act_mask >> f) & 1u;
             const int par = it & 1;
+            // ================= syndrome only, ahead of a check pass that is likely to be a frame's last
+            // (all of whose other work would be thrown away): same stop decision, same iteration count
+            if (FPW == 1 && REG_PRECHECK_T > 0 && unsat <= REG_PRECHECK_T) {
+                if (active && live) {
+                    unsigned long long synd = 0;
+#pragma unroll
+                    for (int c0 = 0; c0 < NS; c0 += 8) {
+                        T p[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int s = c0 + u;
+                            if (s < NS && (!HOLES || ((rmask >> (s / W)) & 1u))) {
+                                const uint32_t ad = (s & 1) ? unpack_addr<1>(rpk[s / 2], post_abs) : unpack_addr<0>(rpk[s / 2], post_abs);
+                                p[u] = lds_load<T>(ad);
+                            }
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int s = c0 + u;
+                            if (s < NS && (!HOLES || ((rmask >> (s / W)) & 1u))) synd ^= __ballot(p[u] > T(0));   // slicer, ldpc.py:47
+                        }
+                    }
+                    if (synd != 0ull && (tid & 63) == 0) flags[par] = 1 << 20;
+                }
+                lds_barrier();
+                if (flags[par] == 0) {
+                    my_iters = it;
+                    my_conv = 1;
+                    break;
+                }
+            }
             // ================= check pass (+ syndrome of the current posterior)
             RowStateRegs<T> nw;
             nw.min1 = INF; nw.min2 = INF; nw.idx = 0; nw.signs = 0;
@@ -357,7 +393,11 @@ qc_regular_kernel(const RegTables tb, const DecodeArgs a)
                 nw.min2 = ms_correct(nw.min2, a.ms_alpha, a.ms_beta);
                 set_wave_prio(0);
                 lds_store_state(smem, my_state, nw);
-                if (synd != 0ull) flags[par * FPW + f] = 1;
+                if (FPW == 1) {             // count of failing rows (bit 20: raised by the syndrome-only pass)
+                    if (synd != 0ull && (tid & 63) == 0) atomicAdd(&flags[par], (int)__popcll(synd));
+                } else if (synd != 0ull) {
+                    flags[par * FPW + f] = 1;
+                }
             }
             lds_barrier();
             // ================= stop test (ldpc.py:332-335), same outcome in every thread
@@ -366,6 +406,7 @@ qc_regular_kernel(const RegTables tb, const DecodeArgs a)
             for (int ff = 0; ff < FPW; ++ff) {
                 if ((act_mask >> ff) & 1u) {
                     const int bad = flags[par * FPW + ff];
+                    if (FPW == 1) unsat = bad & 0xfffff;
                     if (bad != 0 && it < a.max_iters) {
                         next_mask |= 1u << ff;
                     } else if (ff == f) {
