@@ -84,6 +84,9 @@ struct PlanesGeom {
            LDS_BYTES = (DUMMY_OFF + CB + 15) / 16 * 16 };
 };
 
+#ifndef PLANES_PRECHECK_T_SPA
+#define PLANES_PRECHECK_T_SPA 64    // the same for the sum-product kernel, whose check pass costs four times as much
+#endif
 #ifndef PLANES_PRECHECK_T
 #define PLANES_PRECHECK_T 32        // see planes_syndrome_only; 0 = never
 #endif
@@ -508,7 +511,7 @@ planes_role(unsigned char *smem, const PlanesTables &tb, const DecodeArgs &a)
                 int unsat = bad;                              // rows left unsatisfied by the check pass before
                 for (int it = 1;; ++it) {
                     const int par = it & 1;
-                    if (PLANES_PRECHECK_T > 0 && unsat <= PLANES_PRECHECK_T) {
+                    if (PLANES_PRECHECK_T > 0 && unsat <= (SPA ? PLANES_PRECHECK_T_SPA : PLANES_PRECHECK_T)) {
                         if (live) {
                             const unsigned long long synd = planes_syndrome_only<Z, CPT>(smem, radr, synd0);
                             if (synd != 0ull && lane == 0) flags[par] = 1 << 20;
