@@ -331,7 +331,7 @@ slot_minsum_kernel(const SlotTables tb, const DecodeArgs a)
             if (tid == 0) cont[par ^ 1] = 0;
             // plan of the next iteration's syndrome-only pass, laid by the thread of each live frame's row 0
             if (SLOT_PRECHECK_T > 0 && my_act && r == 0) {
-                const int w = wcnt[par * F + f] <= SLOT_PRECHECK_T;
+                const int w = wcnt[par * F + f] <= (a.precheck >= 0 ? a.precheck : SLOT_PRECHECK_T);
                 want[f] = w;
                 preflag[f] = 0;
                 atomicAdd(w ? &n_want[par ^ 1] : &n_not[par ^ 1], 1);

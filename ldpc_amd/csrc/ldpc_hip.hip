@@ -100,6 +100,8 @@ struct DecodeArgs {
                            // frames are decoded one after another (grid of 1 workgroup) and the
                            // check rows' last outgoing messages carry over from frame to frame
     float ms_alpha, ms_beta;   // min-sum magnitude correction: |c2v| = max(alpha*min - beta, 0); 1, 0 = the reference's plain rule
+    int precheck;          // rows left unsatisfied up to which an iteration starts with a syndrome-only pass;
+                           // -1 = each kernel's own default, 0 = never (LDPC_HIP_PRECHECK_T)
     int *work;             // null, or a zeroed counter: workgroups claim frames gridDim.x + atomicAdd(work, 1)
                            // one at a time instead of walking a fixed stride (message-plane kernel)
 };
@@ -814,6 +816,14 @@ accumulate_kernel(int64_t n_frames, const int32_t *iters, const uint8_t *conv, c
         for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
         if ((threadIdx.x & 63) == 0 && v) atomicAdd(&counters[k], v);
     }
+}
+
+// LDPC_HIP_PRECHECK_T: threshold of the syndrome-only pass for every kernel that has one (tuning, and the
+// tests that run it always / never); unset = the kernels' defaults
+static int precheck_override()
+{
+    const char *e = getenv("LDPC_HIP_PRECHECK_T");
+    return (e && e[0]) ? std::max(0, std::min(1 << 19, atoi(e))) : -1;
 }
 
 // ---------------------------------------------------------------- handle
@@ -1607,7 +1617,7 @@ extern "C" int ldpc_decode_device(ldpc_handle *h, int algo, int prec, int sign_m
     a.llr = d_llr; a.llr_f64 = llr_bits == 64; a.llr_scale = llr_scale; a.n_frames = n_frames; a.max_iters = max_iters;
     a.sign_mode = sign_mode; a.hard = d_hard_bits; a.iters = d_iters; a.conv = d_converged;
     a.ones = d_ones; a.soft = d_soft_out; a.chain = nullptr; a.work = nullptr;
-    a.ms_alpha = h->ms_alpha; a.ms_beta = h->ms_beta;
+    a.ms_alpha = h->ms_alpha; a.ms_beta = h->ms_beta; a.precheck = precheck_override();
     return launch_decode(h, algo, prec, a);
 }
 
@@ -1695,7 +1705,7 @@ static int decode_host_pipelined(ldpc_handle *h, unsigned char *chain, int algo,
         a.conv = reinterpret_cast<uint8_t *>(sl.conv.p);
         a.ones = reinterpret_cast<int32_t *>(sl.ones.p);
         a.soft = soft_out ? sl.soft.p : nullptr;
-        a.chain = chain; a.work = nullptr; a.ms_alpha = h->ms_alpha; a.ms_beta = h->ms_beta;
+        a.chain = chain; a.work = nullptr; a.ms_alpha = h->ms_alpha; a.ms_beta = h->ms_beta; a.precheck = precheck_override();
         if ((rc = launch_decode(h, algo, prec, a))) return rc;
         unsigned char *o = static_cast<unsigned char *>(sl.out.p);
         HIP_TRY(hipMemcpyAsync(o + o_hard, sl.hard.p, (size_t)nf * nbytes, hipMemcpyDeviceToHost, h->stream));
@@ -1756,7 +1766,7 @@ static int decode_host(ldpc_handle *h, bool chained, int algo, int prec, int sig
         a.conv = reinterpret_cast<uint8_t *>(h->b_conv.p);
         a.ones = reinterpret_cast<int32_t *>(h->b_ones.p);
         a.soft = soft_out ? h->b_soft.p : nullptr;
-        a.chain = chain; a.work = nullptr; a.ms_alpha = h->ms_alpha; a.ms_beta = h->ms_beta;
+        a.chain = chain; a.work = nullptr; a.ms_alpha = h->ms_alpha; a.ms_beta = h->ms_beta; a.precheck = precheck_override();
         if ((rc = launch_decode(h, algo, prec, a))) return rc;
         if (hard_bits) HIP_TRY(hipMemcpyAsync(hard_bits + (size_t)f0 * nbytes, h->b_hard.p, (size_t)nf * nbytes, hipMemcpyDeviceToHost, h->stream));
         if (iters) HIP_TRY(hipMemcpyAsync(iters + f0, h->b_iters.p, (size_t)nf * 4, hipMemcpyDeviceToHost, h->stream));
@@ -1847,7 +1857,7 @@ extern "C" int ldpc_eval_awgn(ldpc_handle *h, int algo, int prec, int sign_mode,
             a.iters = reinterpret_cast<int32_t *>(h->b_iters.p);
             a.conv = reinterpret_cast<uint8_t *>(h->b_conv.p);
             a.ones = reinterpret_cast<int32_t *>(h->b_ones.p);
-            a.soft = nullptr; a.chain = nullptr; a.work = nullptr; a.ms_alpha = h->ms_alpha; a.ms_beta = h->ms_beta;
+            a.soft = nullptr; a.chain = nullptr; a.work = nullptr; a.ms_alpha = h->ms_alpha; a.ms_beta = h->ms_beta; a.precheck = precheck_override();
             if ((rc = launch_decode(h, algo, prec, a))) return rc;
             const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((nf + 255) / 256, 1024));
             hipLaunchKernelGGL(accumulate_kernel, dim3(grid), dim3(256), 0, h->stream, nf,

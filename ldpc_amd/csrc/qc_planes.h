@@ -509,9 +509,10 @@ planes_role(unsigned char *smem, const PlanesTables &tb, const DecodeArgs &a)
                 lds_barrier();
                 TRACE_IT(-1);
                 int unsat = bad;                              // rows left unsatisfied by the check pass before
+                const int precheck_t = a.precheck >= 0 ? a.precheck : (SPA ? PLANES_PRECHECK_T_SPA : PLANES_PRECHECK_T);   // 0: never (unsat > 0 here)
                 for (int it = 1;; ++it) {
                     const int par = it & 1;
-                    if (PLANES_PRECHECK_T > 0 && unsat <= (SPA ? PLANES_PRECHECK_T_SPA : PLANES_PRECHECK_T)) {
+                    if (unsat <= precheck_t) {
                         if (live) {
                             const unsigned long long synd = planes_syndrome_only<Z, CPT>(smem, radr, synd0);
                             if (synd != 0ull && lane == 0) flags[par] = 1 << 20;

@@ -316,7 +316,7 @@ qc_regular_kernel(const RegTables tb, const DecodeArgs a)
             const int par = it & 1;
             // ================= syndrome only, ahead of a check pass that is likely to be a frame's last
             // (all of whose other work would be thrown away): same stop decision, same iteration count
-            if (FPW == 1 && REG_PRECHECK_T > 0 && unsat <= REG_PRECHECK_T) {
+            if (FPW == 1 && unsat <= (a.precheck >= 0 ? a.precheck : REG_PRECHECK_T)) {     // unsat > 0 here, so 0 means never
                 if (active && live) {
                     unsigned long long synd = 0;
 #pragma unroll

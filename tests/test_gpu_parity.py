@@ -467,3 +467,34 @@ def test_erasures_and_exact_zeros(engines, oracle_mod, name, prec):
     assert np.array_equal(r['hard'], hard)
     assert np.array_equal(r['soft'], soft)
     assert iters[3] == 0 and conv[3] == 1 and iters.max() >= 1
+
+
+@pytest.mark.parametrize('name,prec,algo', [('nearEarth', 32, 0), ('nearEarth', 64, 0), ('nearEarth', 32, 1),
+                                           ('wifi_5_6', 32, 1), ('nearEarth_zero_1_3', 64, 0)])
+def test_syndrome_only_pass_changes_nothing(engines, monkeypatch, name, prec, algo):
+    """Kernels start an iteration with a syndrome-only pass when the pass before left few rows
+    unsatisfied (a frame's last check pass is otherwise thrown away).  Never, by default and before
+    EVERY iteration (LDPC_HIP_PRECHECK_T = 0 / unset / huge): the same bits, iteration counts,
+    status and soft values, frame for frame, at an SNR where frames stop early, late and not at all."""
+    qc, H = build_code(name)
+    n = H.shape[1]
+    snr = 3.3 if name.startswith('nearEarth') else 3.0
+    Y = make_llrs(777, snr, n, 600)
+    if algo == 1:
+        Y = (Y * np.float32(4.0 * 10 ** (snr / 10))).astype(np.float32)      # sum-product takes 2y/sigma^2
+    sign_mode = 0 if name.startswith('nearEarth') else 1
+    eng = engines(name)
+    out = {}
+    for label, value in (('never', '0'), ('default', None), ('always', '500000')):
+        if value is None:
+            monkeypatch.delenv('LDPC_HIP_PRECHECK_T', raising=False)
+        else:
+            monkeypatch.setenv('LDPC_HIP_PRECHECK_T', value)
+        out[label] = eng.decode(Y, 50, prec=prec, algo=algo, sign_mode=sign_mode, want_soft=True)
+    ref = out['never']
+    assert 0 < ref['iters'].min() < ref['iters'].max() and ref['converged'].mean() > 0.2
+    if algo == 0:
+        assert ref['iters'].max() == 50 and ref['converged'].mean() < 1.0
+    for label in ('default', 'always'):
+        for k in ('hard_packed', 'iters', 'converged', 'ones', 'soft'):
+            assert np.array_equal(out[label][k], ref[k]), (label, k)
