@@ -498,3 +498,22 @@ def test_syndrome_only_pass_changes_nothing(engines, monkeypatch, name, prec, al
     for label in ('default', 'always'):
         for k in ('hard_packed', 'iters', 'converged', 'ones', 'soft'):
             assert np.array_equal(out[label][k], ref[k]), (label, k)
+
+
+@pytest.mark.parametrize('name,prec', [('nearEarth', 32), ('nearEarth', 64), ('wifi_5_6', 32)])
+def test_claimed_frames_equal_fixed_stride(engines, monkeypatch, name, prec):
+    """Workgroups claim their next frames from a device counter (frames differ in iteration count);
+    LDPC_HIP_STATIC_FRAMES=1 deals them out in a fixed stride instead.  Which workgroup decodes a
+    frame must not show in any result: a batch several times the grid, both ways."""
+    qc, H = build_code(name)
+    n = H.shape[1]
+    Y = make_llrs(31337, 3.4 if name.startswith('nearEarth') else 3.2, n, 1500 if n > 4000 else 4000)
+    sign_mode = 0 if name.startswith('nearEarth') else 1
+    eng = engines(name)
+    monkeypatch.delenv('LDPC_HIP_STATIC_FRAMES', raising=False)
+    claimed = eng.decode(Y, 50, prec=prec, sign_mode=sign_mode, want_soft=True)
+    monkeypatch.setenv('LDPC_HIP_STATIC_FRAMES', '1')
+    fixed = eng.decode(Y, 50, prec=prec, sign_mode=sign_mode, want_soft=True)
+    for k in ('hard_packed', 'iters', 'converged', 'ones', 'soft'):
+        assert np.array_equal(claimed[k], fixed[k]), k
+    assert claimed['iters'].min() < claimed['iters'].max()
