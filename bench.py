@@ -59,6 +59,32 @@ def cpu_baseline(llr_dev, n_frames, n_threads, slice_frames=16384):
                 mean_iters=float(iters.mean())), iters
 
 
+def launch_ranks(n_ranks, script_argv, timeout=None):
+    """`python bench.py --gpus N` outside a launcher: start N ranks of `script_argv` under
+    torch.distributed.run (one process per GPU, the reference's device fan-out,
+    ldpcCUDA.py:891-906) and hand their exit status back.  The children inherit stdout, so
+    rank 0's JSON line is this process's output.  Called before this process has imported
+    torch or touched HIP: the parent never owns a GPU context."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'LOCAL_WORLD_SIZE', 'MASTER_PORT'):
+        env.pop(k, None)
+    env['MASTER_ADDR'] = '127.0.0.1'
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={int(n_ranks)}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port)] + list(script_argv)
+    sys.stdout.flush()
+    try:
+        return subprocess.run(cmd, env=env, timeout=timeout).returncode
+    except subprocess.TimeoutExpired:
+        return 124
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -77,6 +103,18 @@ def main():
                     help='also time one launch at 0 dB, where every frame runs all 50 iterations (extra field; off by '
                          'default so that a profile of the default command sees only identical launches)')
     args = ap.parse_args()
+
+    # --gpus N with no launcher around this process: start the N ranks here (before torch or HIP
+    # is touched) and relay rank 0's line.  Under torch.distributed.run the launcher's world wins,
+    # and a --gpus that contradicts it is an error rather than a silently mislabelled line.
+    if 'WORLD_SIZE' not in os.environ and 'RANK' not in os.environ:
+        if args.gpus < 1:
+            sys.exit('bench.py: --gpus must be >= 1')
+        if args.gpus > 1:
+            sys.exit(launch_ranks(args.gpus, [os.path.abspath(__file__)] + sys.argv[1:]))
+    elif int(os.environ.get('WORLD_SIZE', '1')) != args.gpus:
+        sys.exit('bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks'
+                 % (args.gpus, os.environ.get('WORLD_SIZE')))
 
     # stdout carries exactly one line, the JSON result: RCCL and gloo print banners straight to file
     # descriptor 1 when a process group comes up, so descriptor 1 points at stderr until the result is ready

@@ -56,3 +56,38 @@ def test_counter_traffic_is_the_algorithmic_traffic():
     d = _load('r01_f32_planes_bench.json')
     # (the bench reads the traffic from the counter summary committed at the time it runs)
     assert abs(d['roofline']['traffic'] - s['hbm_bytes_per_launch']) < 1e-3 * s['hbm_bytes_per_launch']
+
+
+# ---- `bench.py --gpus N` started without a launcher spawns its own ranks
+import subprocess
+import sys
+
+STUB = os.path.join(ROOT, 'tests', 'bench_rank_stub.py')
+
+
+def _launch(mode, n=2):
+    code = ("import sys; sys.path.insert(0, %r); import bench; assert 'torch' not in sys.modules; "
+            "sys.exit(bench.launch_ranks(%d, [%r, %r], timeout=300))" % (ROOT, n, STUB, mode))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE')}
+    return subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+
+
+def test_launch_ranks_relays_rank0_line():
+    p = _launch('ok', 2)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [json.loads(l) for l in p.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    assert lines[0] == {'n_gpus': 2, 'sum': [3, 200], 'master': '127.0.0.1'}
+
+
+def test_launch_ranks_reports_a_failed_rank():
+    p = _launch('fail', 2)
+    assert p.returncode != 0
+    assert not [l for l in p.stdout.splitlines() if l.startswith('{')]
+
+
+def test_gpus_flag_must_match_the_launcher():
+    env = dict(os.environ, WORLD_SIZE='4', RANK='0', LOCAL_RANK='0')
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'], capture_output=True,
+                       text=True, timeout=120, env=env, cwd=ROOT)
+    assert p.returncode != 0 and 'WORLD_SIZE=4' in p.stderr and p.stdout == ''

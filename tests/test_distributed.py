@@ -68,3 +68,24 @@ def test_sharded_sweep_equals_single_process_on_gpu(tmp_path):
     assert one['var'] == two['var']
     cnt = np.array(one['cnt'])
     assert cnt[:, 0].tolist() == [301, 301] and cnt[1, 1] <= cnt[0, 1]
+
+
+@pytest.mark.gpu
+def test_bench_spawns_its_own_ranks():
+    """Plain `python bench.py --gpus 2` (no launcher): two ranks on the one card (gloo rehearsal),
+    one JSON line with n_gpus 2, and counters equal to one rank decoding the same 2F frames."""
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    env['LDPC_BENCH_BACKEND'] = 'gloo'
+
+    def run(gpus, frames):
+        p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(gpus), '--frames', str(frames),
+                            '--steps', '2', '--warmup', '1', '--no-cpu', '--no-secondary'], capture_output=True, text=True,
+                           timeout=600, env=env, cwd=ROOT)
+        assert p.returncode == 0, p.stderr[-3000:]
+        lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
+        assert len(lines) == 1
+        return json.loads(lines[0])
+    two = run(2, 20000)
+    one = run(1, 40000)
+    assert two['n_gpus'] == 2 and one['n_gpus'] == 1
+    assert two['stats'] == one['stats'] and two['stats']['frames'] == 40000
