@@ -98,6 +98,8 @@ def main():
                     help="'spa' times the sum-product kernel instead (secondary figure, not the headline metric)")
     ap.add_argument('--cpu-frames', type=int, default=262144)
     ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--no-secondary', action='store_true',
+                    help='skip the untimed secondary configurations measured after the headline region')
     ap.add_argument('--seed', type=int, default=460101)
     ap.add_argument('--fixed50', action='store_true',
                     help='also time one launch at 0 dB, where every frame runs all 50 iterations (extra field; off by '

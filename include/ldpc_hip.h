@@ -155,6 +155,26 @@ int ldpc_decode_device(ldpc_handle *h, int algo, int prec, int sign_mode, int ma
                        int32_t *d_ones, void *d_soft_out);
 
 /*
+ * ldpc_decode_device for callers that cannot allocate device memory (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the
+ * reference.  Same arguments, outputs and results as ldpc_decode_device; the scratch memory
+ * the kernels need -- the counter workgroups claim their frames from, and the per-workgroup
+ * workspace of the edge-list kernels -- lives in a static device array of
+ * LDPC_NOALLOC_SCRATCH_BYTES that every GPU the library runs on holds until the process ends,
+ * so the call reaches no hipMalloc / hipFree.  A code whose kernel needs a workspace gets as
+ * many workgroups as fit the array (results do not depend on that; it only runs slower).
+ * Fails with LDPC_E_UNSUPPORTED if not even one workspace fits, or if n_frames is beyond
+ * 2^31 - 1 - 4 * (workgroups launched).  All calls on one GPU share the array: two of them
+ * that overlap in time (different handles or streams on the same GPU) race; calls on one
+ * stream, or separated by a synchronisation, are safe.
+ */
+#define LDPC_NOALLOC_SCRATCH_BYTES (4u << 20)
+int ldpc_decode_device_noalloc(ldpc_handle *h, int algo, int prec, int sign_mode, int max_iters,
+                               int64_t n_frames, const void *d_llr, int llr_bits, float llr_scale,
+                               uint8_t *d_hard_bits, int32_t *d_iters, uint8_t *d_converged,
+                               int32_t *d_ones, void *d_soft_out);
+
+/*
  * Fill d_llr [n_frames][n] (device) with BPSK/AWGN channel outputs of the
  * all-zero codeword: y = -1 + sigma*N(0,1), sigma = sqrt(0.5 / 10^(snr_db/10))
  * (ldpc.py:51-66; no code-rate term).  Noise is counter based: sample (frame

@@ -9,7 +9,7 @@ LIB_NAME = 'libldpc_hip.so'
 SYMBOLS = (
     'ldpc_last_error', 'ldpc_device_count', 'ldpc_create_qc', 'ldpc_create_csr', 'ldpc_destroy',
     'ldpc_get_dims', 'ldpc_set_minsum_scaling', 'ldpc_set_stream', 'ldpc_sync', 'ldpc_decode', 'ldpc_decode_chained',
-    'ldpc_reset_state', 'ldpc_decode_device',
+    'ldpc_reset_state', 'ldpc_decode_device', 'ldpc_decode_device_noalloc',
     'ldpc_channel_awgn_device', 'ldpc_eval_awgn', 'ldpc_get_launch_info',
 )
 
@@ -86,6 +86,8 @@ def load():
     L.ldpc_reset_state.argtypes = [vp]
     L.ldpc_decode_device.restype = i32
     L.ldpc_decode_device.argtypes = [vp, i32, i32, i32, i32, i64, vp, i32, flt, vp, vp, vp, vp, vp]
+    L.ldpc_decode_device_noalloc.restype = i32
+    L.ldpc_decode_device_noalloc.argtypes = L.ldpc_decode_device.argtypes
     L.ldpc_channel_awgn_device.restype = i32
     L.ldpc_channel_awgn_device.argtypes = [vp, dbl, u64, u64, i64, vp, vp, vp]
     L.ldpc_eval_awgn.restype = i32

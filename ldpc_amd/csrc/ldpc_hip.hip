@@ -41,6 +41,12 @@
 // ---------------------------------------------------------------- errors
 static thread_local char g_err[512] = "";
 
+// Environment switches that force a slower kernel or a different schedule exist for the parity
+// tests and for A/B timing only.  They are honoured only when LDPC_HIP_TEST_HOOKS=1 was set
+// when the library was loaded; otherwise no decode call reads the environment.
+static const bool g_test_hooks = [] { const char *e = getenv("LDPC_HIP_TEST_HOOKS"); return e && e[0] == '1'; }();
+static const char *hook(const char *name) { return g_test_hooks ? getenv(name) : nullptr; }
+
 static int fail(int code, const char *fmt, ...)
 {
     va_list ap;
@@ -822,7 +828,7 @@ accumulate_kernel(int64_t n_frames, const int32_t *iters, const uint8_t *conv, c
 // tests that run it always / never); unset = the kernels' defaults
 static int precheck_override()
 {
-    const char *e = getenv("LDPC_HIP_PRECHECK_T");
+    const char *e = hook("LDPC_HIP_PRECHECK_T");
     return (e && e[0]) ? std::max(0, std::min(1 << 19, atoi(e))) : -1;
 }
 
@@ -938,6 +944,19 @@ class CopyPool {
     bool stop_ = false;
 };
 
+struct Launch {
+    const void *fn = nullptr;
+    int grid = 0, block = 0, fpw = 1;
+    size_t lds = 0;
+    bool spa_lds = false;     // sum-product: posteriors and messages in LDS (else in the workspace)
+    bool spa_planes = false;  // sum-product on the message-plane kernel
+    bool slots = false;       // short-code kernel on the edge list (edge_slots.h)
+    bool planes = false;      // message-plane kernel (qc_planes.h)
+    bool csr = false;         // csr_minsum_kernel (state in a global workspace)
+    int max_grid = 1;         // workgroups that are resident at once
+    size_t ws_stride = 0;     // bytes of global workspace per workgroup (0: none)
+};
+
 struct ldpc_handle {
     int device = 0;
     int n_cu = 0;
@@ -970,17 +989,10 @@ struct ldpc_handle {
     // pipelined host entry point (large calls only): two slots and a stream for the uploads
     HostSlot slot[2];
     hipStream_t copy_stream = nullptr;
+    unsigned char *scratch = nullptr;   // this device's copy of the static scratch array
+    Launch launch_cache[2][2][2];   // [algo][prec == 64][chained]; fn == nullptr: not chosen yet
 };
 
-struct Launch {
-    const void *fn = nullptr;
-    int grid = 0, block = 0, fpw = 1;
-    size_t lds = 0;
-    bool spa_lds = false;     // sum-product: posteriors and messages in LDS (else in the workspace)
-    bool spa_planes = false;  // sum-product on the message-plane kernel
-    bool slots = false;       // short-code kernel on the edge list (edge_slots.h)
-    bool planes = false;      // message-plane kernel (qc_planes.h)
-};
 
 // posteriors [n] + one message per edge, of the arithmetic type
 static size_t spa_state_bytes(const ldpc_handle *h, int prec)
@@ -999,6 +1011,34 @@ template <typename H> static int upload(ldpc_handle *h, const std::vector<H> &v,
     return 0;
 }
 
+// ---------------------------------------------------------------- scratch of the allocation-free entry point
+// ldpc_decode_device_noalloc keeps the frame-claim counter (first NOALLOC_COUNTER_BYTES) and the
+// per-workgroup workspaces of the edge-list kernels in this array instead of in buffers the
+// handle allocates.  Every GPU the library runs on holds its own copy, at its own address,
+// until the process ends.  In host code the array's name is only a stand-in: device addresses
+// come from hipGetSymbolAddress, once per device, and are kept in g_scratch_ptr.
+static __device__ __align__(256) unsigned char scratch[LDPC_NOALLOC_SCRATCH_BYTES];
+
+enum { MAX_DEVICES = 64 };
+static unsigned char *g_scratch_ptr[MAX_DEVICES];
+static std::mutex g_scratch_mutex;
+
+// Address of `scratch` on `device`, which must be the current device.
+static int scratch_address(int device, unsigned char **out)
+{
+    if (device < 0 || device >= MAX_DEVICES) return fail(LDPC_E_ARG, "device %d beyond the %d this library tracks", device, (int)MAX_DEVICES);
+    std::lock_guard<std::mutex> g(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        void *ptr = nullptr;
+        hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !ptr)
+            return fail(LDPC_E_DEVICE, "hipGetSymbolAddress(scratch) failed on device %d: %s", device, hipGetErrorString(e));
+        g_scratch_ptr[device] = static_cast<unsigned char *>(ptr);
+    }
+    *out = g_scratch_ptr[device];
+    return 0;
+}
+
 static int open_device(int device, ldpc_handle *h)
 {
     int cnt = 0;
@@ -1013,7 +1053,7 @@ static int open_device(int device, ldpc_handle *h)
     h->lds_max = prop.sharedMemPerBlock;
     HIP_TRY(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
     h->stream = h->own_stream;
-    return 0;
+    return scratch_address(device, &h->scratch);     // with `device` current
 }
 
 extern "C" const char *ldpc_last_error(void) { return g_err; }
@@ -1151,7 +1191,7 @@ extern "C" int ldpc_create_qc(int device, int Z, int mb, int nb, const int32_t *
             if (wk != w) regular = false;
         }
         const bool geom = (mb == 2 && nb == 16 && w == 2) || (mb == 4 && nb == 24 && w == 1);
-        const char *force = getenv("LDPC_HIP_FORCE_GENERIC");
+        const char *force = hook("LDPC_HIP_FORCE_GENERIC");
         if (regular && geom && !(force && force[0] == '1')) {
             std::vector<int32_t> sh((size_t)mb * nb * w, 0);
             for (int b = 0; b < mb; ++b)
@@ -1345,7 +1385,7 @@ static int reg_pick(const ldpc_handle *h, Launch *L)
 // float32 NearEarth-shaped codes: explicit messages in LDS (qc_planes.h)
 static bool planes_applies(const ldpc_handle *h, int prec, bool chained)
 {
-    const char *off = getenv("LDPC_HIP_NO_PLANES");
+    const char *off = hook("LDPC_HIP_NO_PLANES");
     return h->planes_ok && prec == 32 && !chained &&
            (size_t)PlanesGeom<511, 8>::LDS_BYTES <= h->lds_max && !(off && off[0] == '1');
 }
@@ -1389,7 +1429,7 @@ static int slots_frames(const ldpc_handle *h)
 
 static bool slots_applies(const ldpc_handle *h, int prec, bool chained)
 {
-    const char *off = getenv("LDPC_HIP_NO_SLOTS");
+    const char *off = hook("LDPC_HIP_NO_SLOTS");
     if (prec != 32 || chained || (off && off[0] == '1')) return false;
     if (h->max_col_deg > 4 || h->max_row_deg > 24 || h->min_row_deg < 2) return false;
     const int F = slots_frames(h);
@@ -1418,27 +1458,40 @@ static int slots_pick(const ldpc_handle *h, bool spa, Launch *L)
     return 0;
 }
 
-static int select_launch(ldpc_handle *h, int algo, int prec, int64_t n_frames, bool chained, Launch *L)
+// Workgroups of `fn` that fit a CU: one attribute call and one occupancy query per
+// (device, kernel, geometry) and process, not per decode call.
+static int blocks_per_cu(int device, const void *fn, int block, size_t lds, int *out)
 {
-    if (algo != LDPC_ALGO_MINSUM && algo != LDPC_ALGO_SUMPRODUCT)
-        return fail(LDPC_E_ARG, "algo must be 0 (min-sum) or 1 (sum-product)");
-    if (prec != 32 && prec != 64) return fail(LDPC_E_ARG, "prec must be 32 or 64");
-    HIP_TRY(hipSetDevice(h->device));
+    struct Key { int device; const void *fn; int block; size_t lds; int per_cu; };
+    static std::mutex mu;
+    static std::vector<Key> seen;
+    std::lock_guard<std::mutex> g(mu);
+    for (const Key &k : seen)
+        if (k.device == device && k.fn == fn && k.block == block && k.lds == lds) { *out = k.per_cu; return 0; }
+    if (lds > 0) HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int per_cu = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, block, lds));
+    if (per_cu < 1) per_cu = 1;
+    seen.push_back(Key{device, fn, block, lds, per_cu});
+    *out = per_cu;
+    return 0;
+}
+
+// Kernel and geometry for (algo, prec, chained) on this handle's code; everything but the grid.
+static int select_kernel(ldpc_handle *h, int algo, int prec, bool chained, Launch *L)
+{
+    int per_cu = 1;
     if (algo == LDPC_ALGO_SUMPRODUCT) {
         if (chained)
             return fail(LDPC_E_UNSUPPORTED, "the re-used-decoder mode exists for min-sum only");
-        const char *edge_only = getenv("LDPC_HIP_SPA_EDGE_LIST");
+        const char *edge_only = hook("LDPC_HIP_SPA_EDGE_LIST");
         const bool fast_ok = !(edge_only && edge_only[0] == '1');
         if (fast_ok && !(h->is_qc && planes_applies(h, prec, false)) && slots_applies(h, prec, false)) {
             // short codes, float32: several frames per workgroup (edge_slots.h)
             int rc = slots_pick(h, true, L);
             if (rc) return rc;
-            HIP_TRY(hipFuncSetAttribute(L->fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L->lds));
-            int per_cu = 0;
-            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, L->fn, L->block, L->lds));
-            if (per_cu < 1) per_cu = 1;
-            const int64_t fblocks = (n_frames + L->fpw - 1) / L->fpw;
-            L->grid = (int)std::max<int64_t>(1, std::min<int64_t>(fblocks, (int64_t)h->n_cu * per_cu));
+            if ((rc = blocks_per_cu(h->device, L->fn, L->block, L->lds, &per_cu))) return rc;
+            L->max_grid = h->n_cu * per_cu;
             return 0;
         }
         if (h->is_qc && planes_applies(h, prec, false) && fast_ok) {
@@ -1446,8 +1499,8 @@ static int select_launch(ldpc_handle *h, int algo, int prec, int64_t n_frames, b
             int rc = planes_pick(h, true, L);
             if (rc) return rc;
             L->spa_planes = true;
-            HIP_TRY(hipFuncSetAttribute(L->fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L->lds));
-            L->grid = (int)std::max<int64_t>(1, std::min<int64_t>(n_frames, (int64_t)h->n_cu));
+            if ((rc = blocks_per_cu(h->device, L->fn, L->block, L->lds, &per_cu))) return rc;
+            L->max_grid = h->n_cu;
             return 0;
         }
         L->fn = prec == 32 ? reinterpret_cast<const void *>(&csr_spa_kernel<float>)
@@ -1457,22 +1510,17 @@ static int select_launch(ldpc_handle *h, int algo, int prec, int64_t n_frames, b
         const size_t need = spa_state_bytes(h, prec);
         L->spa_lds = need + 64 <= h->lds_max;
         L->lds = L->spa_lds ? need : 0;
-        if (L->spa_lds) HIP_TRY(hipFuncSetAttribute(L->fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L->lds));
-        int per_cu = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, L->fn, L->block, L->lds));
-        if (per_cu < 1) per_cu = 1;
-        L->grid = (int)std::max<int64_t>(1, std::min<int64_t>(n_frames, (int64_t)h->n_cu * per_cu));
+        int rc = blocks_per_cu(h->device, L->fn, L->block, L->lds, &per_cu);
+        if (rc) return rc;
+        L->max_grid = h->n_cu * per_cu;
+        L->ws_stride = L->spa_lds ? 0 : ((spa_state_bytes(h, prec) + 255) & ~(size_t)255);
         return 0;
     }
     if (!(h->is_qc && planes_applies(h, prec, chained)) && slots_applies(h, prec, chained)) {
-        int rc = slots_pick(h, algo == LDPC_ALGO_SUMPRODUCT, L);
+        int rc = slots_pick(h, false, L);
         if (rc) return rc;
-        HIP_TRY(hipFuncSetAttribute(L->fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L->lds));
-        int per_cu = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, L->fn, L->block, L->lds));
-        if (per_cu < 1) per_cu = 1;
-        const int64_t fblocks = (n_frames + L->fpw - 1) / L->fpw;
-        L->grid = (int)std::max<int64_t>(1, std::min<int64_t>(fblocks, (int64_t)h->n_cu * per_cu));
+        if ((rc = blocks_per_cu(h->device, L->fn, L->block, L->lds, &per_cu))) return rc;
+        L->max_grid = h->n_cu * per_cu;
         return 0;
     }
     if (h->is_qc) {
@@ -1483,98 +1531,144 @@ static int select_launch(ldpc_handle *h, int algo, int prec, int64_t n_frames, b
         else if (prec == 32) rc = s64 ? qc_select<float, true>(h, chained, L) : qc_select<float, false>(h, chained, L);
         else            rc = s64 ? qc_select<double, true>(h, chained, L) : qc_select<double, false>(h, chained, L);
         if (rc) return rc;
-        if (L->lds > h->lds_max)
-            return fail(LDPC_E_UNSUPPORTED, "code needs %zu bytes of LDS per workgroup, device has %zu", L->lds, h->lds_max);
-        HIP_TRY(hipFuncSetAttribute(L->fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L->lds));
-        int per_cu = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, L->fn, L->block, L->lds));
-        if (per_cu < 1) per_cu = 1;
-        const int64_t fblocks = (n_frames + L->fpw - 1) / L->fpw;
-        L->grid = (int)std::max<int64_t>(1, std::min<int64_t>(fblocks, (int64_t)h->n_cu * per_cu));
-        if (chained) L->grid = 1;
-    } else {
-        L->fn = prec == 32 ? reinterpret_cast<const void *>(&csr_minsum_kernel<float>)
-                           : reinterpret_cast<const void *>(&csr_minsum_kernel<double>);
-        L->block = 256;
-        L->fpw = 1;
-        L->lds = 0;
-        L->grid = (int)std::max<int64_t>(1, std::min<int64_t>(n_frames, (int64_t)h->n_cu * 4));
-        if (chained) L->grid = 1;
+        if (L->lds <= h->lds_max) {
+            if ((rc = blocks_per_cu(h->device, L->fn, L->block, L->lds, &per_cu))) return rc;
+            L->max_grid = h->n_cu * per_cu;
+            return 0;
+        }
+        // the frame state does not fit a CU's LDS in this arithmetic: decode from the edge list
+        // with the state in a global workspace (every QC handle carries its edge list too)
+        *L = Launch();
     }
+    L->fn = prec == 32 ? reinterpret_cast<const void *>(&csr_minsum_kernel<float>)
+                       : reinterpret_cast<const void *>(&csr_minsum_kernel<double>);
+    L->csr = true;
+    L->block = 256;
+    L->fpw = 1;
+    L->lds = 0;
+    L->max_grid = h->n_cu * 4;
+    L->ws_stride = csr_ws_stride(h, prec);
+    return 0;
+}
+
+static int select_launch(ldpc_handle *h, int algo, int prec, int64_t n_frames, bool chained, Launch *L)
+{
+    if (algo != LDPC_ALGO_MINSUM && algo != LDPC_ALGO_SUMPRODUCT)
+        return fail(LDPC_E_ARG, "algo must be 0 (min-sum) or 1 (sum-product)");
+    if (prec != 32 && prec != 64) return fail(LDPC_E_ARG, "prec must be 32 or 64");
+    HIP_TRY(hipSetDevice(h->device));
+    Launch &c = h->launch_cache[algo][prec == 64][chained ? 1 : 0];
+    if (!c.fn || g_test_hooks) {          // (a test hook may change the choice from call to call)
+        Launch fresh;
+        int rc = select_kernel(h, algo, prec, chained, &fresh);
+        if (rc) return rc;
+        c = fresh;
+    }
+    *L = c;
+    const int64_t fblocks = (n_frames + L->fpw - 1) / L->fpw;
+    L->grid = chained ? 1 : (int)std::max<int64_t>(1, std::min<int64_t>(fblocks, (int64_t)L->max_grid));
     return 0;
 }
 
 // Bytes of persistent check-node state of a chained decoder.
 static size_t chain_bytes(const ldpc_handle *h, int prec)
 {
-    if (!h->is_qc) return 0;   // CSR: the whole workspace slice persists (csr_ws_stride)
-    (void)prec;
-    return (size_t)h->qc.mb * h->qc.Zp * 32;   // covers the state layout of either QC kernel
+    // edge-list kernel: its whole workspace slice persists; QC kernels: 32 bytes per row slot
+    // cover the state layout of either of them.  A QC code whose frame state does not fit the
+    // LDS runs on the edge-list kernel, so the buffer is sized for whichever is larger.
+    const size_t qc = h->is_qc ? (size_t)h->qc.mb * h->qc.Zp * 32 : 0;
+    return std::max(qc, csr_ws_stride(h, prec));
 }
 
 // Frames (or blocks of frames) are claimed from a zeroed device counter: they differ in
 // iteration count, and a fixed share per workgroup leaves most CUs idle while the unluckiest
-// one finishes.  LDPC_HIP_STATIC_FRAMES=1 keeps the fixed stride.
-static int claim_counter(ldpc_handle *h, const Launch &L, DecodeArgs *a)
+// one finishes.  LDPC_HIP_STATIC_FRAMES=1 (test hook) keeps the fixed stride.
+// `fixed`: the counter's home when the caller may not allocate (the library's static array).
+static int claim_counter(ldpc_handle *h, const Launch &L, DecodeArgs *a, unsigned char *fixed)
 {
-    const char *fixed = getenv("LDPC_HIP_STATIC_FRAMES");
+    const char *stat = hook("LDPC_HIP_STATIC_FRAMES");
     a->work = nullptr;
-    if (a->n_frames >= (int64_t)0x7fffffff - 4 * (int64_t)L.grid || (fixed && fixed[0] == '1')) return 0;
-    int rc = h->b_work.ensure(256);
-    if (rc) return rc;
-    HIP_TRY(hipMemsetAsync(h->b_work.p, 0, 4, h->stream));
-    a->work = reinterpret_cast<int *>(h->b_work.p);
+    if (a->n_frames >= (int64_t)0x7fffffff - 4 * (int64_t)L.grid) {
+        if (fixed) return fail(LDPC_E_UNSUPPORTED, "n_frames %lld exceeds what the allocation-free entry point takes (2^31 - 1 - 4 * %d)",
+                               (long long)a->n_frames, L.grid);
+        return 0;
+    }
+    if (stat && stat[0] == '1') return 0;
+    void *ctr = fixed;
+    if (!ctr) {
+        int rc = h->b_work.ensure(256);
+        if (rc) return rc;
+        ctr = h->b_work.p;
+    }
+    HIP_TRY(hipMemsetAsync(ctr, 0, 4, h->stream));
+    a->work = reinterpret_cast<int *>(ctr);
     return 0;
 }
 
-static int launch_decode(ldpc_handle *h, int algo, int prec, const DecodeArgs &args)
+// Bytes at the start of the static scratch array that belong to the frame-claim counter; the
+// per-workgroup workspaces of the edge-list kernels follow.
+enum { NOALLOC_COUNTER_BYTES = 256 };
+
+// `fixed` == nullptr: scratch buffers come from the handle (allocated and grown on demand).
+// Otherwise `fixed` points to `fixed_bytes` of device memory that this call may use as its
+// scratch, and nothing is allocated: a kernel that needs a workspace per workgroup gets as
+// many workgroups as fit (results do not depend on the grid), or the call fails.
+static int launch_decode(ldpc_handle *h, int algo, int prec, const DecodeArgs &args,
+                         unsigned char *fixed = nullptr, size_t fixed_bytes = 0)
 {
     Launch L;
     int rc = select_launch(h, algo, prec, args.n_frames, args.chain != nullptr, &L);
     if (rc) return rc;
+    unsigned char *ws = nullptr;
+    if (L.ws_stride && !(L.csr && args.chain)) {
+        if (fixed) {
+            const size_t room = fixed_bytes > NOALLOC_COUNTER_BYTES ? fixed_bytes - NOALLOC_COUNTER_BYTES : 0;
+            const int64_t fit = (int64_t)(room / L.ws_stride);
+            if (fit < 1)
+                return fail(LDPC_E_UNSUPPORTED, "this code needs %zu bytes of workspace per workgroup; the allocation-free "
+                            "entry point has %zu", L.ws_stride, room);
+            L.grid = (int)std::min<int64_t>(L.grid, fit);
+            ws = fixed + NOALLOC_COUNTER_BYTES;
+        } else {
+            if ((rc = h->b_ws.ensure(L.ws_stride * (size_t)L.grid))) return rc;
+            ws = reinterpret_cast<unsigned char *>(h->b_ws.p);
+        }
+    }
+    DecodeArgs a = args;
     if (L.slots) {
         SlotTables tb;
         tb.m = h->m; tb.n = h->n; tb.E = h->E; tb.F = L.fpw;
         tb.row_ptr = h->csr.row_ptr; tb.col_idx = h->csr.col_idx; tb.edge_slot = h->edge_slot;
-        DecodeArgs a = args;
-        if ((rc = claim_counter(h, L, &a))) return rc;
+        if ((rc = claim_counter(h, L, &a, fixed))) return rc;
         void *kargs[] = {&tb, &a};
         HIP_TRY(hipLaunchKernel(L.fn, dim3(L.grid), dim3(L.block), kargs, L.lds, h->stream));
     } else if (L.planes) {
         PlanesTables tb = h->planes;
-        DecodeArgs a = args;
-        if ((rc = claim_counter(h, L, &a))) return rc;
+        if ((rc = claim_counter(h, L, &a, fixed))) return rc;
         void *kargs[] = {&tb, &a};
         HIP_TRY(hipLaunchKernel(L.fn, dim3(L.grid), dim3(L.block), kargs, L.lds, h->stream));
     } else if (algo == LDPC_ALGO_SUMPRODUCT) {
-        size_t stride = (spa_state_bytes(h, prec) + 255) & ~(size_t)255;
-        if (!L.spa_lds && (rc = h->b_ws.ensure(stride * (size_t)L.grid))) return rc;
+        size_t stride = L.ws_stride;
         CsrTables tb = h->csr;
-        DecodeArgs a = args;
-        unsigned char *ws = reinterpret_cast<unsigned char *>(h->b_ws.p);
         int use_lds = L.spa_lds ? 1 : 0;
         void *kargs[] = {&tb, &a, &ws, &stride, &use_lds};
         HIP_TRY(hipLaunchKernel(L.fn, dim3(L.grid), dim3(L.block), kargs, L.lds, h->stream));
-    } else if (h->is_qc && h->is_regular) {
+    } else if (L.csr) {
+        size_t stride = L.ws_stride;
+        CsrTables tb = h->csr;
+        // chained: the persistent buffer IS the workspace of the single workgroup
+        if (args.chain) ws = args.chain;
+        void *kargs[] = {&tb, &a, &ws, &stride};
+        HIP_TRY(hipLaunchKernel(L.fn, dim3(L.grid), dim3(L.block), kargs, 0, h->stream));
+    } else if (h->is_regular) {
         RegTables tb = h->reg;
-        DecodeArgs a = args;
-        if (!a.chain && (rc = claim_counter(h, L, &a))) return rc;      // a re-used decoder takes its frames in order
-        void *kargs[] = {&tb, &a};
-        HIP_TRY(hipLaunchKernel(L.fn, dim3(L.grid), dim3(L.block), kargs, L.lds, h->stream));
-    } else if (h->is_qc) {
-        QcTables tb = h->qc;
-        DecodeArgs a = args;
+        if (!a.chain && (rc = claim_counter(h, L, &a, fixed))) return rc;      // a re-used decoder takes its frames in order
         void *kargs[] = {&tb, &a};
         HIP_TRY(hipLaunchKernel(L.fn, dim3(L.grid), dim3(L.block), kargs, L.lds, h->stream));
     } else {
-        size_t stride = csr_ws_stride(h, prec);
-        if (!args.chain && (rc = h->b_ws.ensure(stride * (size_t)L.grid))) return rc;
-        CsrTables tb = h->csr;
-        DecodeArgs a = args;
-        // chained: the persistent buffer IS the workspace of the single workgroup
-        unsigned char *ws = args.chain ? args.chain : reinterpret_cast<unsigned char *>(h->b_ws.p);
-        void *kargs[] = {&tb, &a, &ws, &stride};
-        HIP_TRY(hipLaunchKernel(L.fn, dim3(L.grid), dim3(L.block), kargs, 0, h->stream));
+        QcTables tb = h->qc;
+        void *kargs[] = {&tb, &a};
+        HIP_TRY(hipLaunchKernel(L.fn, dim3(L.grid), dim3(L.block), kargs, L.lds, h->stream));
     }
     return 0;
 }
@@ -1621,11 +1715,30 @@ extern "C" int ldpc_decode_device(ldpc_handle *h, int algo, int prec, int sign_m
     return launch_decode(h, algo, prec, a);
 }
 
+extern "C" int ldpc_decode_device_noalloc(ldpc_handle *h, int algo, int prec, int sign_mode, int max_iters,
+                                          int64_t n_frames, const void *d_llr, int llr_bits, float llr_scale,
+                                          uint8_t *d_hard_bits, int32_t *d_iters, uint8_t *d_converged,
+                                          int32_t *d_ones, void *d_soft_out)
+{
+    int rc = check_common(h, max_iters, n_frames, sign_mode);
+    if (rc) return rc;
+    if (n_frames == 0) return 0;
+    if (!d_llr) return fail(LDPC_E_ARG, "d_llr is NULL");
+    if (llr_bits != 32 && llr_bits != 64) return fail(LDPC_E_ARG, "llr_bits must be 32 or 64");
+    if (!h->scratch) return fail(LDPC_E_DEVICE, "the static scratch array has no address on device %d", h->device);
+    DecodeArgs a;
+    a.llr = d_llr; a.llr_f64 = llr_bits == 64; a.llr_scale = llr_scale; a.n_frames = n_frames; a.max_iters = max_iters;
+    a.sign_mode = sign_mode; a.hard = d_hard_bits; a.iters = d_iters; a.conv = d_converged;
+    a.ones = d_ones; a.soft = d_soft_out; a.chain = nullptr; a.work = nullptr;
+    a.ms_alpha = h->ms_alpha; a.ms_beta = h->ms_beta; a.precheck = precheck_override();
+    return launch_decode(h, algo, prec, a, h->scratch, (size_t)LDPC_NOALLOC_SCRATCH_BYTES);
+}
+
 static int chain_state(ldpc_handle *h, int prec, unsigned char **out)
 {
     DevBuf &b = prec == 64 ? h->b_chain64 : h->b_chain32;
     if (!b.p) {
-        const size_t bytes = h->is_qc ? chain_bytes(h, prec) : csr_ws_stride(h, prec);
+        const size_t bytes = chain_bytes(h, prec);
         int rc = b.ensure(bytes);
         if (rc) return rc;
         HIP_TRY(hipMemsetAsync(b.p, 0, bytes, h->stream));   // all-zero = fresh check nodes
@@ -1673,7 +1786,7 @@ static int decode_host_pipelined(ldpc_handle *h, unsigned char *chain, int algo,
         if (!sl.done) HIP_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
     }
     int workers = 7;                         // + the calling thread; measured: 4 threads 52, 8 threads 55.5 GB/s
-    if (const char *e = getenv("LDPC_HIP_COPY_THREADS")) workers = std::max(0, std::min(31, atoi(e) - 1));
+    if (const char *e = hook("LDPC_HIP_COPY_THREADS")) workers = std::max(0, std::min(31, atoi(e) - 1));
     CopyPool pool(workers);
     const int64_t n_chunks = (n_frames + chunk - 1) / chunk;
     // results of chunk k: page-locked slot -> caller's arrays
@@ -1733,7 +1846,7 @@ static int decode_host(ldpc_handle *h, bool chained, int algo, int prec, int sig
     HIP_TRY(hipSetDevice(h->device));
     const size_t n = (size_t)h->n, nbytes = (n + 7) / 8, ts = prec == 64 ? 8 : 4, ls = llr_bits / 8;
     // from 128 MB of channel values on, the two-slot pipeline pays for its page-locked staging
-    const char *nopipe = getenv("LDPC_HIP_NO_PIPELINE");
+    const char *nopipe = hook("LDPC_HIP_NO_PIPELINE");
     if ((size_t)n_frames * n * ls >= ((size_t)128 << 20) && !(nopipe && nopipe[0] == '1')) {
         unsigned char *chain0 = nullptr;
         if (chained && (rc = chain_state(h, prec, &chain0))) return rc;

@@ -163,8 +163,11 @@ class Decoder:
     # -- device entry points (pointers: torch CUDA tensors or integer addresses)
     def decode_device(self, d_llr, n_frames, max_iters=50, prec=32, algo=ALGO_MINSUM,
                       sign_mode=SIGN_REFERENCE, llr_scale=1.0, llr_bits=32, d_hard=None, d_iters=None,
-                      d_conv=None, d_ones=None, d_soft=None):
-        _check(self._L.ldpc_decode_device(self._h, algo, prec, sign_mode, int(max_iters), int(n_frames),
+                      d_conv=None, d_ones=None, d_soft=None, noalloc=False):
+        """noalloc=True: the entry point that reaches no hipMalloc (its scratch is a static device
+        array of the library; calls that overlap on one GPU race)."""
+        fn = self._L.ldpc_decode_device_noalloc if noalloc else self._L.ldpc_decode_device
+        _check(fn(self._h, algo, prec, sign_mode, int(max_iters), int(n_frames),
                                           _ptr(d_llr), int(llr_bits), float(llr_scale), _ptr(d_hard), _ptr(d_iters),
                                           _ptr(d_conv), _ptr(d_ones), _ptr(d_soft)))
 

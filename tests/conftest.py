@@ -8,6 +8,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+# the library honours its kernel-forcing / schedule switches (LDPC_HIP_NO_PLANES, ..._PRECHECK_T, ...)
+# only when this is set at load time; the parity tests compare those paths with each other
+os.environ.setdefault('LDPC_HIP_TEST_HOOKS', '1')
 
 
 def pytest_configure(config):
