@@ -175,6 +175,29 @@ def test_edge_cases(engines, oracle_mod):
     assert np.array_equal(r['iters'], iters) and np.array_equal(r['soft'], soft)
 
 
+@pytest.mark.parametrize('name', ['nearEarth', 'nearEarth_zero_1_3', 'nearEarth_mut_w3', 'wifi_5_6'])
+def test_small_iteration_budgets_float32(engines, oracle_mod, name):
+    """The float32 kernels (message planes for the NearEarth shapes, the short-code kernel for 802.11n)
+    with budgets that end a frame before it converges: iterations, status, bits and soft values
+    against the oracle, at an SNR where frames need 4 to 50 iterations."""
+    eng = engines(name)
+    _, H = build_code(name)
+    orc = oracle_mod.Oracle(H)
+    sm = 0 if name in ('nearEarth', 'nearEarth_zero_1_3') else 1
+    Y = make_llrs(5150, 3.4 if name.startswith('nearEarth') else 3.5, H.shape[1], 40)
+    seen = set()
+    for budget in (0, 1, 2, 3, 7):
+        hard, iters, conv, soft = orc.minsum(Y, budget, prec=32, sign_mode=sm, threads=8)
+        r = eng.decode(Y, budget, prec=32, sign_mode=sm, want_soft=True)
+        assert np.array_equal(r['iters'], iters), (name, budget, r['iters'], iters)
+        assert np.array_equal(r['converged'], conv) and np.array_equal(r['hard'], hard)
+        nz = iters > 0          # 0 iterations: the posterior is the input
+        assert np.array_equal(r['soft'][nz], soft[nz])
+        assert np.array_equal(r['soft'][~nz], Y[~nz])
+        seen.add((int(iters.max()), bool(conv.all())))
+    assert (0, False) in seen and (7, False) in seen     # budgets really cut frames short
+
+
 def test_ragged_batches_on_packed_frames(engines, oracle_mod):
     """WiFi frames are packed several to a workgroup; batch sizes that do not fill the last one."""
     eng = engines('wifi_5_6')
