@@ -110,6 +110,16 @@ struct DecodeArgs {
                            // -1 = each kernel's own default, 0 = never (LDPC_HIP_PRECHECK_T)
     int *work;             // null, or a zeroed counter: workgroups claim frames gridDim.x + atomicAdd(work, 1)
                            // one at a time instead of walking a fixed stride (message-plane kernel)
+    // Kernels that make their own channel values (the GEN instantiations; llr is then unused):
+    // frame f of the launch is frame gen_first_frame + f of noise stream (gen_seed, gen_stream),
+    // y = -1 + gen_sigma * z (awgn.h), and the per-frame channel statistics go to
+    unsigned long long gen_seed = 0, gen_first_frame = 0;
+    uint32_t gen_stream = 0;
+    float gen_sigma = 0.0f;
+    int32_t *gen_uncoded = nullptr;              // [frames] channel hard-decision errors, or null
+    unsigned long long *gen_sumsq = nullptr;     // [frames] sum of z^2 in 2^-19 fixed point (awgn.h), or null
+    // null, or [2] summed over the launch: full check passes, syndrome-only passes (measurement only)
+    unsigned long long *pass_counts = nullptr;
 };
 
 // ---------------------------------------------------------------- small helpers
@@ -469,6 +479,7 @@ qc_minsum_kernel(const QcTables tb, const DecodeArgs a)
     }
 }
 
+#include "awgn.h"
 #include "qc_regular.h"
 #include "qc_planes.h"
 #include "edge_slots.h"
@@ -714,36 +725,6 @@ csr_spa_kernel(const CsrTables tb, const DecodeArgs a, unsigned char *workspace,
 }
 
 // ---------------------------------------------------------------- channel kernel
-__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k)
-{
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
-        c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
-        k.x += 0x9E3779B9u;
-        k.y += 0xBB67AE85u;
-    }
-    return c;
-}
-
-__device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
-
-// Four standard normals for positions 4*q .. 4*q+3 of frame `frame`.
-__device__ __forceinline__ float4 normal4(uint64_t seed, uint64_t frame, uint32_t q, uint32_t stream)
-{
-    const uint4 r = philox4x32_10(make_uint4(q, (uint32_t)frame, (uint32_t)(frame >> 32), stream),
-                                  make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
-    // Box-Muller on the hardware transcendental units (log2, sqrt, and sin/cos that take their
-    // argument in revolutions): absolute error ~1e-6, far below the Monte-Carlo resolution,
-    // at a third of the instructions of the library routines
-    const float r0 = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u01(r.x)));   // -2 ln u = -2 ln2 log2 u
-    const float r1 = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u01(r.z)));
-    const float a0 = u01(r.y), a1 = u01(r.w);
-    return make_float4(r0 * __builtin_amdgcn_cosf(a0), r0 * __builtin_amdgcn_sinf(a0),
-                       r1 * __builtin_amdgcn_cosf(a1), r1 * __builtin_amdgcn_sinf(a1));
-}
-
 // y = -1 + sigma*z for the all-zero codeword (modulate: 0 -> -1, ldpc.py:62-66;
 // addAWGN, ldpc.py:51-60).  One workgroup per frame; per-frame sigma_hat
 // (ldpc.py:58) and channel hard-decision errors (ldpcCUDA.py:586-587).
@@ -751,12 +732,12 @@ __global__ void __launch_bounds__(256)
 channel_awgn_kernel(uint64_t seed, uint32_t stream, uint64_t first_frame, int64_t n_frames, int n,
                     float sigma, float *llr, float *sigma_hat, int32_t *uncoded)
 {
-    __shared__ float s_sum[4];
+    __shared__ unsigned long long s_sum[4];
     __shared__ int s_err[4];
     const int tid = threadIdx.x;
     const int nq = (n + 3) >> 2;
     for (int64_t f = blockIdx.x; f < n_frames; f += gridDim.x) {
-        float sum = 0.f;
+        unsigned long long sum = 0;
         int err = 0;
         float *out = llr + f * n;
         for (int q = tid; q < nq; q += blockDim.x) {
@@ -767,7 +748,7 @@ channel_awgn_kernel(uint64_t seed, uint32_t stream, uint64_t first_frame, int64_
             for (int k = 0; k < 4; ++k) {
                 yv[k] = -1.0f + nz[k];
                 if (4 * q + k < n) {
-                    sum += nz[k] * nz[k];
+                    sum += awgn_sq_fixed(k == 0 ? z.x : k == 1 ? z.y : k == 2 ? z.z : z.w);
                     err += yv[k] > 0.f;
                 }
             }
@@ -785,8 +766,7 @@ channel_awgn_kernel(uint64_t seed, uint32_t stream, uint64_t first_frame, int64_
         if ((tid & 63) == 0) { s_sum[tid >> 6] = sum; s_err[tid >> 6] = err; }
         __syncthreads();
         if (tid == 0) {
-            const float t = (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]);
-            if (sigma_hat) sigma_hat[f] = sqrtf(t / (float)n);
+            if (sigma_hat) sigma_hat[f] = awgn_sigma_hat(s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3], sigma, n);
             if (uncoded) uncoded[f] = s_err[0] + s_err[1] + s_err[2] + s_err[3];
         }
         __syncthreads();
@@ -795,8 +775,8 @@ channel_awgn_kernel(uint64_t seed, uint32_t stream, uint64_t first_frame, int64_
 
 // counters[6]: frames, frame errors, decoded bit errors, iterations, uncoded bit errors, not-a-codeword
 __global__ void __launch_bounds__(256)
-accumulate_kernel(int64_t n_frames, const int32_t *iters, const uint8_t *conv, const int32_t *ones,
-                  const int32_t *uncoded, const float *sigma_hat,
+accumulate_kernel(int64_t n_frames, int n, float sigma, const int32_t *iters, const uint8_t *conv, const int32_t *ones,
+                  const int32_t *uncoded, const float *sigma_hat, const unsigned long long *sumsq,
                   unsigned long long *counters, float *per_frame)
 {
     unsigned long long c[6] = {0, 0, 0, 0, 0, 0};
@@ -810,7 +790,7 @@ accumulate_kernel(int64_t n_frames, const int32_t *iters, const uint8_t *conv, c
         c[5] += conv[f] == 0;
         if (per_frame) {
             float *p = per_frame + 4 * f;
-            p[0] = sigma_hat[f];
+            p[0] = sumsq ? awgn_sigma_hat(sumsq[f], sigma, n) : sigma_hat[f];      // a decode kernel that made its own noise leaves the sum
             p[1] = (float)uncoded[f];
             p[2] = (float)ones[f];
             p[3] = (float)iters[f];
@@ -946,6 +926,7 @@ class CopyPool {
 
 struct Launch {
     const void *fn = nullptr;
+    const void *fn_gen = nullptr;   // the same kernel generating its own channel values (sweep driver), if it exists
     int grid = 0, block = 0, fpw = 1;
     size_t lds = 0;
     bool spa_lds = false;     // sum-product: posteriors and messages in LDS (else in the workspace)
@@ -983,7 +964,7 @@ struct ldpc_handle {
     int max_col_deg = 0, min_row_deg = 0;
     std::vector<void *> tables;   // device allocations owned by the handle
     // staging for the host entry points
-    DevBuf b_llr, b_hard, b_iters, b_conv, b_ones, b_soft, b_sig, b_unc, b_cnt, b_pf, b_ws, b_work;
+    DevBuf b_llr, b_hard, b_iters, b_conv, b_ones, b_soft, b_sig, b_sq, b_unc, b_cnt, b_pf, b_ws, b_work;
     // check-node state of the chained (stateful) decoder, one per arithmetic width
     DevBuf b_chain32, b_chain64;
     // pipelined host entry point (large calls only): two slots and a stream for the uploads
@@ -1072,7 +1053,7 @@ extern "C" void ldpc_destroy(ldpc_handle *h)
     if (h->own_stream) { (void)hipStreamSynchronize(h->own_stream); }
     for (void *p : h->tables) (void)hipFree(p);
     DevBuf *bufs[] = {&h->b_llr, &h->b_hard, &h->b_iters, &h->b_conv, &h->b_ones, &h->b_soft,
-                      &h->b_sig, &h->b_unc, &h->b_cnt, &h->b_pf, &h->b_ws, &h->b_chain32, &h->b_chain64, &h->b_work};
+                      &h->b_sig, &h->b_sq, &h->b_unc, &h->b_cnt, &h->b_pf, &h->b_ws, &h->b_chain32, &h->b_chain64, &h->b_work};
     for (DevBuf *b : bufs) b->release();
     if (h->copy_stream) { (void)hipStreamSynchronize(h->copy_stream); (void)hipStreamDestroy(h->copy_stream); }
     for (HostSlot &sl : h->slot) {
@@ -1392,8 +1373,10 @@ static bool planes_applies(const ldpc_handle *h, int prec, bool chained)
 
 static int planes_pick(const ldpc_handle *h, bool spa, Launch *L)
 {
-    L->fn = spa ? reinterpret_cast<const void *>(&qc_planes_kernel<511, 8, true>)
-                : reinterpret_cast<const void *>(&qc_planes_kernel<511, 8, false>);
+    L->fn = spa ? reinterpret_cast<const void *>(&qc_planes_kernel<511, 8, true, false>)
+                : reinterpret_cast<const void *>(&qc_planes_kernel<511, 8, false, false>);
+    L->fn_gen = spa ? reinterpret_cast<const void *>(&qc_planes_kernel<511, 8, true, true>)
+                    : reinterpret_cast<const void *>(&qc_planes_kernel<511, 8, false, true>);
     L->planes = true;
     L->block = 2 * PlanesGeom<511, 8>::ZP;
     L->fpw = 1;
@@ -1499,7 +1482,9 @@ static int select_kernel(ldpc_handle *h, int algo, int prec, bool chained, Launc
             int rc = planes_pick(h, true, L);
             if (rc) return rc;
             L->spa_planes = true;
-            if ((rc = blocks_per_cu(h->device, L->fn, L->block, L->lds, &per_cu))) return rc;
+            if ((rc = blocks_per_cu(h->device, L->fn, L->block, L->lds, &per_cu)) ||
+                (rc = blocks_per_cu(h->device, L->fn_gen, L->block, L->lds, &per_cu)))
+                return rc;
             L->max_grid = h->n_cu;
             return 0;
         }
@@ -1533,6 +1518,7 @@ static int select_kernel(ldpc_handle *h, int algo, int prec, bool chained, Launc
         if (rc) return rc;
         if (L->lds <= h->lds_max) {
             if ((rc = blocks_per_cu(h->device, L->fn, L->block, L->lds, &per_cu))) return rc;
+            if (L->fn_gen && (rc = blocks_per_cu(h->device, L->fn_gen, L->block, L->lds, &per_cu))) return rc;
             L->max_grid = h->n_cu * per_cu;
             return 0;
         }
@@ -1619,6 +1605,7 @@ static int launch_decode(ldpc_handle *h, int algo, int prec, const DecodeArgs &a
     Launch L;
     int rc = select_launch(h, algo, prec, args.n_frames, args.chain != nullptr, &L);
     if (rc) return rc;
+    if (!args.llr && !L.fn_gen) return fail(LDPC_E_UNSUPPORTED, "this kernel does not generate its own channel values");
     unsigned char *ws = nullptr;
     if (L.ws_stride && !(L.csr && args.chain)) {
         if (fixed) {
@@ -1646,7 +1633,7 @@ static int launch_decode(ldpc_handle *h, int algo, int prec, const DecodeArgs &a
         PlanesTables tb = h->planes;
         if ((rc = claim_counter(h, L, &a, fixed))) return rc;
         void *kargs[] = {&tb, &a};
-        HIP_TRY(hipLaunchKernel(L.fn, dim3(L.grid), dim3(L.block), kargs, L.lds, h->stream));
+        HIP_TRY(hipLaunchKernel(a.llr ? L.fn : L.fn_gen, dim3(L.grid), dim3(L.block), kargs, L.lds, h->stream));
     } else if (algo == LDPC_ALGO_SUMPRODUCT) {
         size_t stride = L.ws_stride;
         CsrTables tb = h->csr;
@@ -1945,24 +1932,31 @@ extern "C" int ldpc_eval_awgn(ldpc_handle *h, int algo, int prec, int sign_mode,
     if (n_snr == 0 || frames_per_snr == 0) return 0;
     HIP_TRY(hipSetDevice(h->device));
     const size_t n = (size_t)h->n;
-    const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(frames_per_snr, (int64_t)(((size_t)8192 << 20) / (n * 4)) + 1));
-    if ((rc = h->b_llr.ensure((size_t)chunk * n * 4)) || (rc = h->b_iters.ensure((size_t)chunk * 4)) ||
+    // Where the decode kernel can make its own channel values (message-plane kernels) a sweep point is
+    // one launch that reads nothing from HBM; elsewhere the channel kernel fills a buffer of at most
+    // 8 GiB that the decode kernel then reads.  Same noise either way (LDPC_HIP_NO_FUSED_CHANNEL=1, a
+    // test hook, forces the second form).
+    Launch L;
+    if ((rc = select_launch(h, algo, prec, frames_per_snr, false, &L))) return rc;
+    const char *unfused = hook("LDPC_HIP_NO_FUSED_CHANNEL");
+    const bool fused = L.fn_gen != nullptr && !(unfused && unfused[0] == '1');
+    const int64_t cap = fused ? ((int64_t)1 << 24) : (int64_t)(((size_t)8192 << 20) / (n * 4)) + 1;
+    const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(frames_per_snr, cap));
+    if ((rc = h->b_iters.ensure((size_t)chunk * 4)) ||
         (rc = h->b_conv.ensure((size_t)chunk)) || (rc = h->b_ones.ensure((size_t)chunk * 4)) ||
-        (rc = h->b_sig.ensure((size_t)chunk * 4)) || (rc = h->b_unc.ensure((size_t)chunk * 4)) ||
+        (rc = h->b_unc.ensure((size_t)chunk * 4)) ||
         (rc = h->b_cnt.ensure(sizeof(uint64_t) * 6 * (size_t)n_snr)))
+        return rc;
+    if (fused ? (rc = h->b_sq.ensure((size_t)chunk * 8))
+              : ((rc = h->b_llr.ensure((size_t)chunk * n * 4)) || (rc = h->b_sig.ensure((size_t)chunk * 4))))
         return rc;
     if (per_frame && (rc = h->b_pf.ensure((size_t)chunk * 16))) return rc;
     HIP_TRY(hipMemsetAsync(h->b_cnt.p, 0, sizeof(uint64_t) * 6 * (size_t)n_snr, h->stream));
     for (int s = 0; s < n_snr; ++s) {
         for (int64_t f0 = 0; f0 < frames_per_snr; f0 += chunk) {
             const int64_t nf = std::min<int64_t>(chunk, frames_per_snr - f0);
-            if ((rc = launch_channel(h, snr_db[s], seed, (uint32_t)s, first_frame + (uint64_t)f0, nf,
-                                     reinterpret_cast<float *>(h->b_llr.p),
-                                     reinterpret_cast<float *>(h->b_sig.p),
-                                     reinterpret_cast<int32_t *>(h->b_unc.p))))
-                return rc;
             DecodeArgs a;
-            a.llr = h->b_llr.p; a.llr_f64 = 0; a.n_frames = nf;
+            a.llr_f64 = 0; a.n_frames = nf;
             // min-sum works on the raw channel values like the reference (ldpc.py:371-377: no scaling);
             // sum-product needs true log-likelihood ratios, 2y/sigma^2 for BPSK on AWGN
             a.llr_scale = algo == LDPC_ALGO_SUMPRODUCT ? (float)(4.0 * pow(10.0, snr_db[s] / 10.0)) : 1.0f;
@@ -1971,14 +1965,30 @@ extern "C" int ldpc_eval_awgn(ldpc_handle *h, int algo, int prec, int sign_mode,
             a.conv = reinterpret_cast<uint8_t *>(h->b_conv.p);
             a.ones = reinterpret_cast<int32_t *>(h->b_ones.p);
             a.soft = nullptr; a.chain = nullptr; a.work = nullptr; a.ms_alpha = h->ms_alpha; a.ms_beta = h->ms_beta; a.precheck = precheck_override();
+            if (fused) {
+                a.llr = nullptr;
+                a.gen_seed = seed; a.gen_stream = (uint32_t)s; a.gen_first_frame = first_frame + (uint64_t)f0;
+                a.gen_sigma = (float)sqrt(0.5 / pow(10.0, snr_db[s] / 10.0));      // ldpc.py:53-55
+                a.gen_uncoded = reinterpret_cast<int32_t *>(h->b_unc.p);
+                a.gen_sumsq = reinterpret_cast<unsigned long long *>(h->b_sq.p);
+            } else {
+                if ((rc = launch_channel(h, snr_db[s], seed, (uint32_t)s, first_frame + (uint64_t)f0, nf,
+                                         reinterpret_cast<float *>(h->b_llr.p),
+                                         reinterpret_cast<float *>(h->b_sig.p),
+                                         reinterpret_cast<int32_t *>(h->b_unc.p))))
+                    return rc;
+                a.llr = h->b_llr.p;
+            }
             if ((rc = launch_decode(h, algo, prec, a))) return rc;
             const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((nf + 255) / 256, 1024));
-            hipLaunchKernelGGL(accumulate_kernel, dim3(grid), dim3(256), 0, h->stream, nf,
+            hipLaunchKernelGGL(accumulate_kernel, dim3(grid), dim3(256), 0, h->stream, nf, h->n,
+                               (float)sqrt(0.5 / pow(10.0, snr_db[s] / 10.0)),
                                reinterpret_cast<const int32_t *>(h->b_iters.p),
                                reinterpret_cast<const uint8_t *>(h->b_conv.p),
                                reinterpret_cast<const int32_t *>(h->b_ones.p),
                                reinterpret_cast<const int32_t *>(h->b_unc.p),
-                               reinterpret_cast<const float *>(h->b_sig.p),
+                               fused ? nullptr : reinterpret_cast<const float *>(h->b_sig.p),
+                               fused ? reinterpret_cast<const unsigned long long *>(h->b_sq.p) : nullptr,
                                reinterpret_cast<unsigned long long *>(h->b_cnt.p) + 6 * s,
                                per_frame ? reinterpret_cast<float *>(h->b_pf.p) : nullptr);
             HIP_TRY(hipGetLastError());

@@ -81,7 +81,10 @@ struct PlanesGeom {
            REC_BYTES = N * CB, SHTAB_OFF = REC_BYTES, SHTAB_BYTES = MB * NB * W * 4,
            FLAG_OFF = SHTAB_OFF + SHTAB_BYTES,
            DUMMY_OFF = FLAG_OFF + 16,                // record every edge of a zeroed circulant points to
-           LDS_BYTES = (DUMMY_OFF + CB + 15) / 16 * 16 };
+           GEN_OFF = DUMMY_OFF + CB,                 // kernels that make their own noise: uncoded errors (4 bytes), then
+                                                     // the frame's sum of squared noise (8 bytes, 8-byte aligned)
+           LDS_BYTES = (GEN_OFF + 12 + 15) / 16 * 16 };
+    static_assert((GEN_OFF + 4) % 8 == 0, "the 64-bit noise sum must be 8-byte aligned");
 };
 
 #ifndef PLANES_PRECHECK_T_SPA
@@ -328,7 +331,9 @@ planes_check_pass_spa(unsigned char *smem, const uint32_t (&radr)[CPT * 4], int 
 // once per B and the kernel branches ONCE (wave-uniformly) into its copy: with one shared
 // loop and a branch per pass the optimiser merges the common tails of the copies and
 // carries every per-edge intermediate across the merge in registers.
-template <int Z, int CPT, int B, bool SPA>
+// GEN: the kernel makes its own channel values (BPSK/AWGN of the all-zero codeword, awgn.h) instead
+// of reading them: the sweep driver then touches HBM for its per-frame results only.
+template <int Z, int CPT, int B, bool SPA, bool GEN>
 __device__ __forceinline__ void
 planes_role(unsigned char *smem, const PlanesTables &tb, const DecodeArgs &a)
 {
@@ -414,7 +419,7 @@ planes_role(unsigned char *smem, const PlanesTables &tb, const DecodeArgs &a)
     float y[CPT], ynext[CPT];
 #pragma unroll
     for (int q = 0; q < CPT; ++q) ynext[q] = 0.0f;
-    if (live && (int64_t)blockIdx.x < n_frames)
+    if (!GEN && live && (int64_t)blockIdx.x < n_frames)
         planes_load_frame<CPT>(a.llr, a.llr_f64, (int64_t)blockIdx.x * N, (uint32_t)(g * Z + ic), MB * Z, ynext);
 #pragma unroll
     for (int q = 0; q < CPT; ++q) {
@@ -423,6 +428,46 @@ planes_role(unsigned char *smem, const PlanesTables &tb, const DecodeArgs &a)
         y[q] = ynext[q] * a.llr_scale + 0.0f;
     }
     if (tid < 4) flags[tid] = 0;
+    if (GEN && tid == 0) {
+        lds_put_u32(smem, G::GEN_OFF, 0u);
+        *reinterpret_cast<unsigned long long *>(smem + G::GEN_OFF + 4) = 0ull;
+    }
+    if (GEN) lds_barrier();
+    // GEN: the frame's channel values go straight into the posterior slots, position by position
+    // (one generator call makes 4 consecutive positions; thread t takes calls t and t + NT), with
+    // the same keying and arithmetic as the stand-alone channel kernel, so both give the same frame.
+    static_assert(!GEN || N % 4 == 0, "generator calls cover 4 positions each");
+    auto generate_frame = [&](int64_t frame) {
+        uint32_t sq = 0;                 // this thread's 8 samples: < 2^28 in 2^-19 fixed point
+        int err = 0;                     // wave-uniform: channel hard-decision errors of the wave
+#pragma unroll
+        for (int hh = 0; hh < (N / 4 + NT - 1) / NT; ++hh) {
+            const uint32_t qb = (uint32_t)tid + (uint32_t)hh * NT;
+            if (qb < (uint32_t)(N / 4)) {
+                const float4 z = normal4(a.gen_seed, a.gen_first_frame + (uint64_t)frame, qb, a.gen_stream);
+                const float zz[4] = {z.x, z.y, z.z, z.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float yv = -1.0f + a.gen_sigma * zz[k];
+                    sq += awgn_sq_fixed(zz[k]);
+                    err += (int)__popcll(__ballot(yv > 0.f));
+                    lds_put_f32(smem, (4u * qb + (uint32_t)k) * CB, yv * a.llr_scale + 0.0f);
+                }
+            }
+        }
+        sq = awgn_row_sum16(sq);         // < 2^32 per row of 16 lanes
+        const unsigned long long wsq = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)sq, 15) +
+                                       (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)sq, 31) +
+                                       (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)sq, 47) +
+                                       (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)sq, 63);
+        if (lane == 0) {
+            atomicAdd(reinterpret_cast<int *>(smem + G::GEN_OFF), err);
+            atomicAdd(reinterpret_cast<unsigned long long *>(smem + G::GEN_OFF + 4), wsq);
+        }
+    };
+    int cur_unc = 0, out_unc = 0;
+    unsigned long long cur_sq = 0, out_sq = 0;
+    uint32_t n_full = 0, n_synd = 0;             // check passes of this workgroup (a.pass_counts)
 
     // Results of the previous frame, held in registers until the next frame's first check pass
     // is under way.  A CU takes thousands of cycles to queue one frame's worth of global
@@ -452,6 +497,8 @@ planes_role(unsigned char *smem, const PlanesTables &tb, const DecodeArgs &a)
             if (a.iters) a.iters[out_frame] = out_iters;
             if (a.conv) a.conv[out_frame] = (uint8_t)out_conv;
             if (a.ones) a.ones[out_frame] = out_ones;
+            if (GEN && a.gen_uncoded) a.gen_uncoded[out_frame] = out_unc;
+            if (GEN && a.gen_sumsq) a.gen_sumsq[out_frame] = out_sq;
         }
     };
 
@@ -468,14 +515,28 @@ planes_role(unsigned char *smem, const PlanesTables &tb, const DecodeArgs &a)
 #endif
     for (int64_t frame = blockIdx.x, next_frame = 0; frame < n_frames; frame = next_frame) {
         TRACE(0);
+        if (GEN) {
+            generate_frame(frame);
+        } else {
 #pragma unroll
-        for (int q = 0; q < CPT; ++q)
-            if (live) lds_put_f32(smem, (q < 4 ? cadr0 : cadr1) + (uint32_t)(q & 3) * (MB * Z * CB), y[q]);
+            for (int q = 0; q < CPT; ++q)
+                if (live) lds_put_f32(smem, (q < 4 ? cadr0 : cadr1) + (uint32_t)(q & 3) * (MB * Z * CB), y[q]);
+        }
         if (tid < 3) flags[tid] = 0;                      // two stop flags, ones counter
         int my_iters = 0, my_conv = 0;
         TRACE(1);
         lds_barrier();
         TRACE(2);
+        if (GEN) {
+            // my columns' channel values, for the variable passes; the frame's channel statistics
+#pragma unroll
+            for (int q = 0; q < CPT; ++q)
+                y[q] = lds_f32(smem, (q < 4 ? cadr0 : cadr1) + (uint32_t)(q & 3) * (MB * Z * CB));
+            cur_unc = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int *>(smem + G::GEN_OFF));
+            const unsigned long long sqv = *reinterpret_cast<const unsigned long long *>(smem + G::GEN_OFF + 4);
+            cur_sq = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(sqv >> 32)) << 32) |
+                     (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)sqv);
+        }
         // claim the frame after this one; the answer is needed only after the check pass below
         int claimed = 0;
         if (a.work && tid == 0) claimed = atomicAdd(a.work, 1);
@@ -492,13 +553,14 @@ planes_role(unsigned char *smem, const PlanesTables &tb, const DecodeArgs &a)
                 if (synd != 0ull && lane == 0) atomicAdd(&flags[0], (int)__popcll(synd));
             }
             if (a.work && tid == 0) flags[3] = claimed;
+            ++n_full;
             TRACE(4);
             lds_barrier();
             TRACE(5);
             next_frame = frame + gridDim.x;
             if (a.work) next_frame = (int64_t)gridDim.x + __builtin_amdgcn_readfirstlane(flags[3]);
             // the next frame's channel values: requested now, used when this frame is done
-            if (live && next_frame < n_frames)
+            if (!GEN && live && next_frame < n_frames)
                 planes_load_frame<CPT>(a.llr, a.llr_f64, next_frame * N, (uint32_t)(g * Z + ic), MB * Z, ynext);
             const int bad = __builtin_amdgcn_readfirstlane(flags[0]);
             if (bad == 0 || a.max_iters <= 0) {
@@ -513,6 +575,7 @@ planes_role(unsigned char *smem, const PlanesTables &tb, const DecodeArgs &a)
                 for (int it = 1;; ++it) {
                     const int par = it & 1;
                     if (unsat <= precheck_t) {
+                        ++n_synd;
                         if (live) {
                             const unsigned long long synd = planes_syndrome_only<Z, CPT>(smem, radr, synd0);
                             if (synd != 0ull && lane == 0) flags[par] = 1 << 20;
@@ -530,6 +593,7 @@ planes_role(unsigned char *smem, const PlanesTables &tb, const DecodeArgs &a)
                             : planes_check_pass<Z, CPT, B, false>(smem, radr, D, a.sign_mode, ic, synd0, a.ms_alpha, a.ms_beta);
                         if (synd != 0ull && lane == 0) atomicAdd(&flags[par], (int)__popcll(synd));
                     }
+                    ++n_full;
                     TRACE_IT(0);
                     lds_barrier();
                     TRACE_IT(1);
@@ -580,14 +644,21 @@ planes_role(unsigned char *smem, const PlanesTables &tb, const DecodeArgs &a)
 #endif
         }
         TRACE(7);
+        if (!GEN) {
 #pragma unroll
-        for (int q = 0; q < CPT; ++q) y[q] = ynext[q] * a.llr_scale + 0.0f;
+            for (int q = 0; q < CPT; ++q) y[q] = ynext[q] * a.llr_scale + 0.0f;
+        } else if (tid == 0) {
+            lds_put_u32(smem, G::GEN_OFF, 0u);
+            *reinterpret_cast<unsigned long long *>(smem + G::GEN_OFF + 4) = 0ull;
+        }
 #ifdef LDPC_TRACE
         asm volatile("" : "+v"(y[0]), "+v"(y[7]));
 #endif
         TRACE(8);
         lds_barrier();
         TRACE(9);
+        out_unc = cur_unc;
+        out_sq = cur_sq;
         out_bits = mine;
         out_frame = frame;
         out_iters = my_iters;
@@ -603,6 +674,10 @@ planes_role(unsigned char *smem, const PlanesTables &tb, const DecodeArgs &a)
 #endif
     }
     flush_outputs();
+    if (a.pass_counts && tid == 0) {
+        atomicAdd(&a.pass_counts[0], (unsigned long long)n_full);
+        atomicAdd(&a.pass_counts[1], (unsigned long long)n_synd);
+    }
 #ifdef LDPC_TRACE
     // phase sums of this wave over all its frames -> [workgroup][wave][12] in the soft-output buffer
     if (lane == 0 && a.soft)
@@ -614,13 +689,13 @@ planes_role(unsigned char *smem, const PlanesTables &tb, const DecodeArgs &a)
 #endif
 }
 
-template <int Z, int CPT, bool SPA>
+template <int Z, int CPT, bool SPA, bool GEN>
 __global__ void __launch_bounds__(1024)
 qc_planes_kernel(const PlanesTables tb, const DecodeArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (__builtin_amdgcn_readfirstlane(threadIdx.x / PlanesGeom<Z, CPT>::ZP) == 0)
-        planes_role<Z, CPT, 0, SPA>(smem, tb, a);
+        planes_role<Z, CPT, 0, SPA, GEN>(smem, tb, a);
     else
-        planes_role<Z, CPT, 1, SPA>(smem, tb, a);
+        planes_role<Z, CPT, 1, SPA, GEN>(smem, tb, a);
 }

@@ -540,3 +540,25 @@ def test_claimed_frames_equal_fixed_stride(engines, monkeypatch, name, prec):
     for k in ('hard_packed', 'iters', 'converged', 'ones', 'soft'):
         assert np.array_equal(claimed[k], fixed[k]), k
     assert claimed['iters'].min() < claimed['iters'].max()
+
+
+@pytest.mark.parametrize('name', ['nearEarth', 'nearEarth_zero_1_3'])
+def test_fused_channel_sweep_equals_unfused(engines, monkeypatch, name):
+    """The sweep driver's decode kernel makes its own channel values where it can (message-plane
+    kernels); LDPC_HIP_NO_FUSED_CHANNEL=1 runs the channel kernel into a buffer first.  Same noise
+    stream, same arithmetic: counters and every per-frame column (sigma_hat, uncoded, decoded,
+    iterations) must be identical, for min-sum and sum-product, whatever the frame window."""
+    eng = engines(name)
+    for algo in (0, 1):
+        for first, F in ((0, 1500), (123457, 700)):
+            monkeypatch.delenv('LDPC_HIP_NO_FUSED_CHANNEL', raising=False)
+            c1, p1 = eng.eval_awgn([3.0, 3.5], F, seed=5, first_frame=first, per_frame=True, algo=algo)
+            monkeypatch.setenv('LDPC_HIP_NO_FUSED_CHANNEL', '1')
+            c2, p2 = eng.eval_awgn([3.0, 3.5], F, seed=5, first_frame=first, per_frame=True, algo=algo)
+            monkeypatch.delenv('LDPC_HIP_NO_FUSED_CHANNEL')
+            assert np.array_equal(c1, c2), (algo, c1, c2)
+            assert np.array_equal(p1, p2)
+            assert c1[0, 3] > c1[1, 3] > 0 and (c1[:, 0] == F).all()
+    # sigma_hat is the sample RMS of the noise (ldpc.py:58): close to sigma, frame by frame
+    sigma = np.sqrt(0.5 / 10 ** 0.35)
+    assert np.allclose(p1[1, :, 0], sigma, rtol=0.05) and p1[1, :, 0].std() > 0
