@@ -957,6 +957,7 @@ struct ldpc_handle {
     // message-plane kernel (2 x 16 circulants of size 511, every weight <= 2)
     float ms_alpha = 1.0f, ms_beta = 0.0f;     // min-sum magnitude correction (ldpc_set_minsum_scaling)
     bool planes_ok = false;
+    bool planes_heavy = false;     // some circulant has weight > 2 (extra edges through a global scratch row)
     PlanesTables planes{};
     // CSR
     CsrTables csr{};
@@ -1198,21 +1199,46 @@ extern "C" int ldpc_create_qc(int device, int Z, int mb, int nb, const int32_t *
         return rc;
     }
     if (mb == 2 && nb == 16 && Z == 511) {
-        bool light = true;
-        for (int k = 0; k < nblk; ++k) light = light && (blk_ptr[k + 1] - blk_ptr[k] <= 2);
-        if (light) {
-            std::vector<int32_t> sh((size_t)mb * nb * 2, 0);
+        // message-plane kernel: weights 0..2 directly; up to PLANES_MAXW with the shifts beyond the two
+        // lowest as "extra edges", at most PLANES_MAXX of them per block-row
+        bool fits = true;
+        int n_extra[2] = {0, 0};
+        for (int b = 0; b < mb; ++b)
+            for (int j = 0; j < nb; ++j) {
+                const int w = blk_ptr[b * nb + j + 1] - blk_ptr[b * nb + j];
+                fits = fits && w <= PLANES_MAXW;
+                n_extra[b] += std::max(0, w - 2);
+            }
+        fits = fits && n_extra[0] <= PLANES_MAXX && n_extra[1] <= PLANES_MAXX;
+        if (fits) {
+            std::vector<int32_t> sh((size_t)mb * nb * 2, 0), colsum((size_t)nb * 2 * (1 + PLANES_MAXW), 0);
+            int nx[2] = {0, 0};
             for (int b = 0; b < mb; ++b)
                 for (int j = 0; j < nb; ++j) {
                     std::vector<int32_t> v(shifts + blk_ptr[b * nb + j], shifts + blk_ptr[b * nb + j + 1]);
                     std::sort(v.begin(), v.end());
+                    int32_t *cs = &colsum[((size_t)j * 2 + b) * (1 + PLANES_MAXW)];
+                    cs[0] = (int32_t)v.size();
                     for (size_t k = 0; k < v.size(); ++k) {
-                        sh[((size_t)b * nb + j) * 2 + k] = v[k];
-                        h->planes.edge_mask[b] |= 1u << (2 * j + (int)k);
+                        int src;
+                        if (k < 2) {
+                            sh[((size_t)b * nb + j) * 2 + k] = v[k];
+                            h->planes.edge_mask[b] |= 1u << (2 * j + (int)k);
+                            src = (int)k;
+                        } else {
+                            h->planes.extra[b][nx[b]] = j | (v[k] << 8);
+                            src = 2 + nx[b]++;
+                            h->planes.heavy_cols |= 1u << j;
+                        }
+                        cs[1 + (v.size() - 1 - k)] = v[k] | (src << 16);      // descending shift order
                     }
                 }
-            if ((rc = upload(h, sh, &h->planes.shifts))) { ldpc_destroy(h); return rc; }
+            h->planes.n_extra[0] = n_extra[0];
+            h->planes.n_extra[1] = n_extra[1];
+            h->planes.xstride = (uint32_t)(n_extra[0] + n_extra[1]) * PLANES_XROW;
+            if ((rc = upload(h, sh, &h->planes.shifts)) || (rc = upload(h, colsum, &h->planes.colsum))) { ldpc_destroy(h); return rc; }
             h->planes_ok = true;
+            h->planes_heavy = h->planes.heavy_cols != 0;
         }
     }
     // the same graph as an edge list, columns ascending inside a row (used by the sum-product kernel)
@@ -1364,19 +1390,25 @@ static int reg_pick(const ldpc_handle *h, Launch *L)
 }
 
 // float32 NearEarth-shaped codes: explicit messages in LDS (qc_planes.h)
-static bool planes_applies(const ldpc_handle *h, int prec, bool chained)
+static bool planes_applies(const ldpc_handle *h, int prec, bool chained, bool spa = false)
 {
     const char *off = hook("LDPC_HIP_NO_PLANES");
-    return h->planes_ok && prec == 32 && !chained &&
+    return h->planes_ok && prec == 32 && !chained && !(spa && h->planes_heavy) &&
            (size_t)PlanesGeom<511, 8>::LDS_BYTES <= h->lds_max && !(off && off[0] == '1');
 }
 
 static int planes_pick(const ldpc_handle *h, bool spa, Launch *L)
 {
-    L->fn = spa ? reinterpret_cast<const void *>(&qc_planes_kernel<511, 8, true, false>)
-                : reinterpret_cast<const void *>(&qc_planes_kernel<511, 8, false, false>);
-    L->fn_gen = spa ? reinterpret_cast<const void *>(&qc_planes_kernel<511, 8, true, true>)
-                    : reinterpret_cast<const void *>(&qc_planes_kernel<511, 8, false, true>);
+    if (h->planes_heavy) {
+        L->fn = reinterpret_cast<const void *>(&qc_planes_kernel<511, 8, false, false, true>);
+        L->fn_gen = reinterpret_cast<const void *>(&qc_planes_kernel<511, 8, false, true, true>);
+        L->ws_stride = (size_t)h->planes.xstride * sizeof(float);
+    } else {
+        L->fn = spa ? reinterpret_cast<const void *>(&qc_planes_kernel<511, 8, true, false, false>)
+                    : reinterpret_cast<const void *>(&qc_planes_kernel<511, 8, false, false, false>);
+        L->fn_gen = spa ? reinterpret_cast<const void *>(&qc_planes_kernel<511, 8, true, true, false>)
+                        : reinterpret_cast<const void *>(&qc_planes_kernel<511, 8, false, true, false>);
+    }
     L->planes = true;
     L->block = 2 * PlanesGeom<511, 8>::ZP;
     L->fpw = 1;
@@ -1469,7 +1501,7 @@ static int select_kernel(ldpc_handle *h, int algo, int prec, bool chained, Launc
             return fail(LDPC_E_UNSUPPORTED, "the re-used-decoder mode exists for min-sum only");
         const char *edge_only = hook("LDPC_HIP_SPA_EDGE_LIST");
         const bool fast_ok = !(edge_only && edge_only[0] == '1');
-        if (fast_ok && !(h->is_qc && planes_applies(h, prec, false)) && slots_applies(h, prec, false)) {
+        if (fast_ok && !(h->is_qc && planes_applies(h, prec, false, true)) && slots_applies(h, prec, false)) {
             // short codes, float32: several frames per workgroup (edge_slots.h)
             int rc = slots_pick(h, true, L);
             if (rc) return rc;
@@ -1477,7 +1509,7 @@ static int select_kernel(ldpc_handle *h, int algo, int prec, bool chained, Launc
             L->max_grid = h->n_cu * per_cu;
             return 0;
         }
-        if (h->is_qc && planes_applies(h, prec, false) && fast_ok) {
+        if (h->is_qc && planes_applies(h, prec, false, true) && fast_ok) {
             // float32 NearEarth-shaped codes: message planes in LDS, hardware transcendentals
             int rc = planes_pick(h, true, L);
             if (rc) return rc;
@@ -1631,6 +1663,7 @@ static int launch_decode(ldpc_handle *h, int algo, int prec, const DecodeArgs &a
         HIP_TRY(hipLaunchKernel(L.fn, dim3(L.grid), dim3(L.block), kargs, L.lds, h->stream));
     } else if (L.planes) {
         PlanesTables tb = h->planes;
+        tb.xmsg = reinterpret_cast<float *>(ws);          // heavy circulants: the workgroups' scratch rows
         if ((rc = claim_counter(h, L, &a, fixed))) return rc;
         void *kargs[] = {&tb, &a};
         HIP_TRY(hipLaunchKernel(a.llr ? L.fn : L.fn_gen, dim3(L.grid), dim3(L.block), kargs, L.lds, h->stream));

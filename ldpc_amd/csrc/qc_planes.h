@@ -69,9 +69,41 @@ planes_load_frame(const void *llr, int is_f64, int64_t frame_base, uint32_t firs
 #define PLANES_VB 2                 // columns per batch of the variable pass (measured: 2 < 4 < 1 < 8)
 #endif
 
+// Heavy circulants (weight 3 .. PLANES_MAXW: what a gym action with up to 7 hot bits installs,
+// ldpc_env.py:293-317): the two lowest shifts of such a block use its two message slots like any
+// other block; its further shifts are "extra edges".  A row of block-row b has n_extra[b] of them
+// (at most PLANES_MAXX).  The row thread keeps their record addresses in registers and rebuilds the
+// messages it sent along them last time from the row's compressed state {min1, min2, argmin,
+// signs}; what it sends goes to a per-workgroup scratch row in global memory (the LDS is full),
+// from where the column's owner adds it in the variable pass.
+enum { PLANES_MAXX = 8, PLANES_MAXW = 8, PLANES_XROW = 512 };
+
 struct PlanesTables {
     uint32_t edge_mask[2];   // [block-row] bit 2j+k set: shift k of circulant (b, j) exists (weight 0, 1 or 2)
     const int32_t *shifts;   // [2][NB][2] ascending inside a circulant; entries of missing shifts unused
+    // ---- heavy circulants only (HEAVY kernels)
+    int n_extra[2];                  // extra edges per row of block-row b
+    int32_t extra[2][PLANES_MAXX];   // block-column | shift << 8
+    uint32_t heavy_cols;             // bit j: block-column j holds a heavy circulant
+    const int32_t *colsum;           // [NB][2][1 + PLANES_MAXW]: per (block-column, block-row) the number of shifts, then
+                                     // shift | source << 16 in DESCENDING shift order; source 0, 1: message slot, 2 + x: extra x
+    float *xmsg;                     // scratch [workgroup][n_extra[0] + n_extra[1]][PLANES_XROW] extra-edge messages
+    uint32_t xstride;                // floats per workgroup in xmsg
+};
+
+// A row's extra edges (HEAVY kernels): record addresses, and the compressed form of what the row
+// sent along them in the previous iteration
+struct PlanesXState {
+    uint32_t xadr2[PLANES_MAXX / 2]; // record addresses / 4, two to a register (they are below 2^18 and multiples of 4)
+    __device__ __forceinline__ uint32_t xadr(int x) const
+    {
+        return (x & 1) ? (xadr2[x >> 1] >> 14) & 0x3fffcu : (xadr2[x >> 1] << 2) & 0x3fffcu;
+    }
+    float pm1, pm2;                  // the two magnitudes sent
+    uint32_t pidx;                   // edge that got pm2: 0..31 slot edges, 32 + x extra x
+    uint32_t psign;                  // bit x: the message on extra x was negative
+    float *xrow;                     // scratch of my row: extra x at xrow[x * PLANES_XROW]
+    int X;                           // number of extra edges (uniform)
 };
 
 template <int Z, int CPT>
@@ -98,12 +130,18 @@ struct PlanesGeom {
 // last check pass finds every parity satisfied and all its other work is thrown away; when the pass
 // before left no more than PLANES_PRECHECK_T rows unsatisfied, this much cheaper pass is run first
 // and the full one only if it still finds a failing row.  Same stop decision, same iteration count.
-template <int Z, int CPT>
+template <int Z, int CPT, bool HEAVY>
 __device__ __forceinline__ unsigned long long
-planes_syndrome_only(const unsigned char *smem, const uint32_t (&radr)[CPT * 4], unsigned long long synd0)
+planes_syndrome_only(const unsigned char *smem, const uint32_t (&radr)[CPT * 4], unsigned long long synd0,
+                     const PlanesXState &xs)
 {
     enum { NS = CPT * 4, CHS = 8 };
     unsigned long long synd = synd0;
+    if (HEAVY) {
+#pragma unroll
+        for (int x = 0; x < PLANES_MAXX; ++x)
+            if (x < xs.X) synd ^= __ballot(lds_f32(smem, xs.xadr(x)) > 0.0f);
+    }
 #pragma unroll
     for (int s0 = 0; s0 < NS; s0 += CHS) {
         float p[CHS];
@@ -118,10 +156,10 @@ planes_syndrome_only(const unsigned char *smem, const uint32_t (&radr)[CPT * 4],
 // Check pass of one row of block-row B.  FIRST: the row's previous messages are all +0
 // (fresh decoder, checkNode.__init__ ldpc.py:121) and are not read.  Returns the lanes
 // whose parity check on the current hard decisions fails.
-template <int Z, int CPT, int B, bool FIRST>
+template <int Z, int CPT, int B, bool FIRST, bool HEAVY>
 __device__ __forceinline__ unsigned long long
 planes_check_pass(unsigned char *smem, const uint32_t (&radr)[CPT * 4], int D, int sign_mode, int ic,
-                  unsigned long long synd0, float alpha, float beta)
+                  unsigned long long synd0, float alpha, float beta, PlanesXState &xs)
 {
     typedef PlanesGeom<Z, CPT> G;
     enum { NS = G::NS, CH = PLANES_CH, NCH = NS / CH };
@@ -129,6 +167,30 @@ planes_check_pass(unsigned char *smem, const uint32_t (&radr)[CPT * 4], int D, i
     float min1 = INF, min2 = INF;
     uint32_t idx = 0, R = 0;
     unsigned long long synd = synd0;     // set for every row if rows have an odd number of missing edges (each reads as hard decision 1)
+    uint32_t RX = 0;                     // bit x: v < 0 on extra edge x
+    if (HEAVY) {
+        // The extra edges first (minimum, second minimum and sign product do not depend on the order
+        // edges are visited in; equal magnitudes make min2 == min1, so neither does the result of argmin).
+        float px[PLANES_MAXX];
+#pragma unroll
+        for (int x = 0; x < PLANES_MAXX; ++x) px[x] = x < xs.X ? lds_f32(smem, xs.xadr(x)) : 0.0f;
+#pragma unroll
+        for (int x = 0; x < PLANES_MAXX; ++x) {
+            if (x < xs.X) {
+                synd ^= __ballot(px[x] > 0.0f);
+                float v = px[x];
+                if (!FIRST) {
+                    const uint32_t mag = xs.pidx == (uint32_t)(NS + x) ? __float_as_uint(xs.pm2) : __float_as_uint(xs.pm1);
+                    v = px[x] - __uint_as_float(mag | (((xs.psign >> x) & 1u) << 31));     // receive, ldpc.py:161
+                }
+                RX |= (__float_as_uint(v) >> 31) << x;
+                const float av = fabsf(v);
+                idx = av < min1 ? (uint32_t)(NS + x) : idx;
+                min2 = __builtin_amdgcn_fmed3f(min1, min2, av);
+                min1 = fminf(min1, av);
+            }
+        }
+    }
     // Software pipeline over chunks of CH edges: the LDS reads of chunk k+1 are in flight
     // while chunk k is reduced, so a wave's own LDS latency is covered even when its three
     // SIMD neighbours are waiting too (right after a barrier all of them are).
@@ -188,6 +250,7 @@ planes_check_pass(unsigned char *smem, const uint32_t (&radr)[CPT * 4], int D, i
     // a bit of T is then the sign of the outgoing message itself (ldpc.py:190)
     if (NS < 32) R <<= (32 - NS);
     uint32_t S = __popc(R) & 1u;
+    if (HEAVY) S ^= __popc(RX) & 1u;
     if (sign_mode == LDPC_SIGN_CORRECTED) S ^= (uint32_t)D & 1u;       // D: the row's real degree
     const uint32_t full = 0xffffffffu << (32 - NS);
     const uint32_t T = R ^ (S ? full : 0u);
@@ -196,8 +259,17 @@ planes_check_pass(unsigned char *smem, const uint32_t (&radr)[CPT * 4], int D, i
         min2 = ms_correct(min2, alpha, beta);
     }
     const uint32_t m1 = __float_as_uint(min1), m2 = __float_as_uint(min2);
+    if (HEAVY) {
+        // extra edges: +-min1, or +-min2 on the arg-min edge (ldpc.py:190-191), to the scratch row
+        const uint32_t SX = RX ^ (S ? 0xffffffffu : 0u);
+#pragma unroll
+        for (int x = 0; x < PLANES_MAXX; ++x)
+            if (x < xs.X)
+                xs.xrow[x * PLANES_XROW] = __uint_as_float((idx == (uint32_t)(NS + x) ? m2 : m1) | (((SX >> x) & 1u) << 31));
+        xs.pm1 = min1; xs.pm2 = min2; xs.pidx = idx; xs.psign = SX;
+    }
     // shift of the arg-min edge, needed after the loop below (idx differs from lane to lane)
-    const uint32_t ej = idx >> 1, ek = idx & 1u;
+    const uint32_t ej = (HEAVY ? idx & (uint32_t)(NS - 1) : idx) >> 1, ek = idx & 1u;
     const int esh = *reinterpret_cast<const int *>(smem + G::SHTAB_OFF + ((B * G::NB + ej) * 2 + ek) * 4);
     // every edge gets +-min1 ...
 #pragma unroll
@@ -213,8 +285,9 @@ planes_check_pass(unsigned char *smem, const uint32_t (&radr)[CPT * 4], int D, i
         int ci = ic + esh;
         ci = ci >= Z ? ci - Z : ci;
         const uint32_t adr = (uint32_t)(ej * Z + ci) * G::CB + 4u * (1 + 2 * B) + 4u * ek;
-        const uint32_t rank = idx;
-        if (D > 0) lds_put_u32(smem, adr, m2 | ((T << rank) & 0x80000000u));     // D == 0: every edge is a dummy
+        const uint32_t rank = idx & 31u;
+        if (D > 0 && (!HEAVY || idx < (uint32_t)NS))          // D == 0: every edge is a dummy; HEAVY: the arg-min may be an extra edge
+            lds_put_u32(smem, adr, m2 | ((T << rank) & 0x80000000u));
     }
     return synd;
 }
@@ -333,10 +406,11 @@ planes_check_pass_spa(unsigned char *smem, const uint32_t (&radr)[CPT * 4], int 
 // carries every per-edge intermediate across the merge in registers.
 // GEN: the kernel makes its own channel values (BPSK/AWGN of the all-zero codeword, awgn.h) instead
 // of reading them: the sweep driver then touches HBM for its per-frame results only.
-template <int Z, int CPT, int B, bool SPA, bool GEN>
+template <int Z, int CPT, int B, bool SPA, bool GEN, bool HEAVY>
 __device__ __forceinline__ void
 planes_role(unsigned char *smem, const PlanesTables &tb, const DecodeArgs &a)
 {
+    static_assert(!(HEAVY && SPA), "heavy circulants: min-sum only");
     typedef PlanesGeom<Z, CPT> G;
     enum { MB = G::MB, W = G::W, NB = G::NB, NS = G::NS, N = G::N, ZP = G::ZP, CB = G::CB,
            NT = MB * G::ZP };                    // threads per workgroup
@@ -356,8 +430,25 @@ planes_role(unsigned char *smem, const PlanesTables &tb, const DecodeArgs &a)
     // ---- per-launch set-up
     for (int x = tid; x < MB * NB * W; x += NT) shtab[x] = tb.shifts[x];
     const uint32_t emask = g == 0 ? tb.edge_mask[0] : tb.edge_mask[1];   // existing edges of a row of my block-row
-    const int D = __popc(emask);
-    const unsigned long long synd0 = ((NS - D) & 1) ? __ballot(live) : 0ull;   // only lanes that own a row
+    PlanesXState xs;
+    xs.X = HEAVY ? tb.n_extra[B] : 0;
+    xs.pm1 = xs.pm2 = 0.0f; xs.pidx = 0; xs.psign = 0; xs.xrow = nullptr;
+    if (HEAVY) {
+        float *mine = tb.xmsg + (size_t)blockIdx.x * tb.xstride;
+        xs.xrow = mine + (size_t)(B == 0 ? 0 : tb.n_extra[0]) * PLANES_XROW + ic;
+#pragma unroll
+        for (int x = 0; x < PLANES_MAXX; ++x) {
+            const int e = tb.extra[B][x];
+            int c = ic + (e >> 8);
+            c = c >= Z ? c - Z : c;
+            const uint32_t adr = x < xs.X ? (uint32_t)((e & 0xff) * Z + c) * CB : (uint32_t)G::DUMMY_OFF;
+            if (x & 1) xs.xadr2[x >> 1] |= (adr >> 2) << 16;
+            else xs.xadr2[x >> 1] = adr >> 2;
+        }
+        static_assert(G::LDS_BYTES < (1 << 18) && G::DUMMY_OFF % 4 == 0 && CB % 4 == 0, "packed record addresses");
+    }
+    const int D = __popc(emask) + xs.X;                                 // the row's real degree
+    const unsigned long long synd0 = ((NS - __popc(emask)) & 1) ? __ballot(live) : 0ull;   // only lanes that own a row
     // once per launch: message slots (those of zeroed circulants are never written again) and the dummy record
     for (int x = tid; x < N; x += NT)
 #pragma unroll
@@ -384,9 +475,60 @@ planes_role(unsigned char *smem, const PlanesTables &tb, const DecodeArgs &a)
         if (ic >= s0 && ic < s1) lomask |= 1u << q;
     }
 
+    // HEAVY: columns of a block-column that holds a heavy circulant are summed in full by these two
+    // steps: per block-row all messages of the column's block in ascending check index
+    // (ldpc.py:298-303) -- shifts descending, first the rows c - s that do not wrap (s <= c), then
+    // the wrapped ones.  heavy_fetch reads the messages (slots from LDS, extra edges from the scratch
+    // rows in global memory), heavy_sum adds them and writes the posterior.
+    const float *xw = HEAVY ? tb.xmsg + (size_t)blockIdx.x * tb.xstride : nullptr;
+    auto heavy_fetch = [&](int j, float (&m)[2][PLANES_MAXW]) {
+        const uint32_t adr = cadr0 + (uint32_t)(j >> 1) * (MB * Z * CB);
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int32_t *cs = tb.colsum + (j * 2 + b) * (1 + PLANES_MAXW);
+            const int cnt = cs[0];
+            const float *xb = xw + (size_t)(b == 0 ? 0 : tb.n_extra[0]) * PLANES_XROW;
+#pragma unroll
+            for (int k = 0; k < PLANES_MAXW; ++k) {
+                m[b][k] = 0.0f;
+                if (k < cnt) {
+                    const int e = cs[1 + k], sh = e & 0xffff, src = e >> 16;
+                    int r = ic - sh;
+                    r = r < 0 ? r + Z : r;
+                    m[b][k] = src < 2 ? lds_f32(smem, adr + 4u * (uint32_t)(1 + 2 * b + src))
+                                      : xb[(src - 2) * PLANES_XROW + r];
+                }
+            }
+        }
+    };
+    auto heavy_sum = [&](int j, const float (&m)[2][PLANES_MAXW], const float (&y)[CPT]) {
+        const int q = j >> 1;
+        float acc = 0.0f;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int32_t *cs = tb.colsum + (j * 2 + b) * (1 + PLANES_MAXW);
+            const int cnt = cs[0];
+#pragma unroll
+            for (int k = 0; k < PLANES_MAXW; ++k)
+                if (k < cnt && (cs[1 + k] & 0xffff) <= ic) acc = acc + m[b][k];
+#pragma unroll
+            for (int k = 0; k < PLANES_MAXW; ++k)
+                if (k < cnt && (cs[1 + k] & 0xffff) > ic) acc = acc + m[b][k];
+        }
+        float yq = y[0];
+#pragma unroll
+        for (int qq = 1; qq < CPT; ++qq) yq = q == qq ? y[qq] : yq;
+        lds_put_f32(smem, cadr0 + (uint32_t)q * (MB * Z * CB), acc + yq);     // channel last, ldpc.py:322
+    };
+    const uint32_t my_heavy = HEAVY ? tb.heavy_cols & (B == 0 ? 0x55555555u : 0xaaaaaaaau) : 0u;   // my block-columns: j = g + 2q
+
     // variable pass (ldpc.py:295-311, 321-323): columns (g + q*MB, ic)
     auto variable_pass = [&](const float (&y)[CPT]) {
         enum { VB = PLANES_VB };                               // columns per batch: loads first, then sums
+        // HEAVY: the first heavy block-column's messages are requested now and added after the regular
+        // columns, whose work covers the latency of the scratch rows
+        float hm[2][PLANES_MAXW];
+        if (HEAVY && my_heavy) heavy_fetch(__builtin_ctz(my_heavy), hm);
 #pragma unroll
         for (int q0 = 0; q0 < CPT; q0 += VB) {
             set_wave_prio(VB < CPT ? 3 - q0 * 3 / (CPT - VB + (VB == CPT)) : 3);
@@ -411,6 +553,16 @@ planes_role(unsigned char *smem, const PlanesTables &tb, const DecodeArgs &a)
                 lds_put_f32(smem, adr, acc + y[q]);               // channel last, ldpc.py:322
             }
             __builtin_amdgcn_sched_barrier(0);
+        }
+        if (HEAVY && my_heavy) {
+            heavy_sum(__builtin_ctz(my_heavy), hm, y);
+            uint32_t todo = my_heavy & (my_heavy - 1);
+            while (todo) {
+                const int j = __builtin_ctz(todo);
+                todo &= todo - 1;
+                heavy_fetch(j, hm);
+                heavy_sum(j, hm, y);
+            }
         }
     };
 
@@ -548,13 +700,14 @@ planes_role(unsigned char *smem, const PlanesTables &tb, const DecodeArgs &a)
             if (live) {
                 const unsigned long long synd = SPA
                     ? planes_check_pass_spa<Z, CPT, B, true>(smem, radr, D, a.sign_mode, synd0)
-                    : planes_check_pass<Z, CPT, B, true>(smem, radr, D, a.sign_mode, ic, synd0, a.ms_alpha, a.ms_beta);
+                    : planes_check_pass<Z, CPT, B, true, HEAVY>(smem, radr, D, a.sign_mode, ic, synd0, a.ms_alpha, a.ms_beta, xs);
                 // flags[parity]: number of rows whose check fails (bit 20: raised by the syndrome-only pass)
                 if (synd != 0ull && lane == 0) atomicAdd(&flags[0], (int)__popcll(synd));
             }
             if (a.work && tid == 0) flags[3] = claimed;
             ++n_full;
             TRACE(4);
+            if (HEAVY) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the extra edges' messages have left for the scratch rows
             lds_barrier();
             TRACE(5);
             next_frame = frame + gridDim.x;
@@ -577,7 +730,7 @@ planes_role(unsigned char *smem, const PlanesTables &tb, const DecodeArgs &a)
                     if (unsat <= precheck_t) {
                         ++n_synd;
                         if (live) {
-                            const unsigned long long synd = planes_syndrome_only<Z, CPT>(smem, radr, synd0);
+                            const unsigned long long synd = planes_syndrome_only<Z, CPT, HEAVY>(smem, radr, synd0, xs);
                             if (synd != 0ull && lane == 0) flags[par] = 1 << 20;
                         }
                         lds_barrier();
@@ -590,11 +743,12 @@ planes_role(unsigned char *smem, const PlanesTables &tb, const DecodeArgs &a)
                     if (live) {
                         const unsigned long long synd = SPA
                             ? planes_check_pass_spa<Z, CPT, B, false>(smem, radr, D, a.sign_mode, synd0)
-                            : planes_check_pass<Z, CPT, B, false>(smem, radr, D, a.sign_mode, ic, synd0, a.ms_alpha, a.ms_beta);
+                            : planes_check_pass<Z, CPT, B, false, HEAVY>(smem, radr, D, a.sign_mode, ic, synd0, a.ms_alpha, a.ms_beta, xs);
                         if (synd != 0ull && lane == 0) atomicAdd(&flags[par], (int)__popcll(synd));
                     }
                     ++n_full;
                     TRACE_IT(0);
+                    if (HEAVY) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     lds_barrier();
                     TRACE_IT(1);
                     const int bad2 = __builtin_amdgcn_readfirstlane(flags[par]);   // stop test, ldpc.py:332-335
@@ -689,13 +843,13 @@ planes_role(unsigned char *smem, const PlanesTables &tb, const DecodeArgs &a)
 #endif
 }
 
-template <int Z, int CPT, bool SPA, bool GEN>
+template <int Z, int CPT, bool SPA, bool GEN, bool HEAVY>
 __global__ void __launch_bounds__(1024)
 qc_planes_kernel(const PlanesTables tb, const DecodeArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (__builtin_amdgcn_readfirstlane(threadIdx.x / PlanesGeom<Z, CPT>::ZP) == 0)
-        planes_role<Z, CPT, 0, SPA, GEN>(smem, tb, a);
+        planes_role<Z, CPT, 0, SPA, GEN, HEAVY>(smem, tb, a);
     else
-        planes_role<Z, CPT, 1, SPA, GEN>(smem, tb, a);
+        planes_role<Z, CPT, 1, SPA, GEN, HEAVY>(smem, tb, a);
 }

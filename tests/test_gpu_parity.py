@@ -562,3 +562,61 @@ def test_fused_channel_sweep_equals_unfused(engines, monkeypatch, name):
     # sigma_hat is the sample RMS of the noise (ldpc.py:58): close to sigma, frame by frame
     sigma = np.sqrt(0.5 / 10 ** 0.35)
     assert np.allclose(p1[1, :, 0], sigma, rtol=0.05) and p1[1, :, 0].std() > 0
+
+
+def test_heavy_circulants_on_the_message_plane_kernel(oracle_mod, monkeypatch):
+    """Circulants of weight 3..8 (what a gym action with up to 7 hot bits installs, ldpc_env.py:293-317):
+    float32 stays on the message-plane kernel, the shifts beyond a block's two lowest as extra edges
+    through a global scratch row.  Bit-identical to the oracle for both sign rules, with heavy blocks
+    in either block-row, two in one block-column, beside zeroed and light ones, at the limits (weight
+    8, 8 extra edges in a block-row) -- and identical to the table-driven kernel, which takes over
+    beyond those limits."""
+    import ldpc_amd
+    from ldpc_amd import codes
+    base = codes.near_earth()
+    prng = np.random.RandomState(511)
+    hot = lambda w: sorted(prng.choice(511, w, replace=False).tolist())
+    variants = [
+        base.with_block(0, 5, hot(3)),
+        base.with_block(1, 9, hot(7)).with_block(0, 12, hot(1)),
+        base.with_block(0, 3, hot(4)).with_block(1, 3, hot(5)),                      # both blocks of one block-column
+        base.with_block(0, 0, hot(8)).with_block(0, 15, []).with_block(1, 8, hot(3)).with_block(1, 2, [0]),
+        base.with_block(1, 14, hot(6)).with_block(1, 1, hot(6)),                      # 8 extra edges in block-row 1
+        base.with_block(0, 7, [0, 1, 510]).with_block(1, 7, [509, 510, 0, 1]),        # shifts that wrap for almost every row
+    ]
+    for qc in variants:
+        H = qc.to_dense()
+        orc = oracle_mod.Oracle(H)
+        Y = make_llrs(4321, 3.4, qc.n, 24)
+        Y[5, :64] = 0.0
+        with ldpc_amd.Decoder(qc) as eng:
+            assert eng.launch_info(prec=32)['lds_bytes'] == 163824, qc.row_degrees()      # the message-plane kernel
+            for sm in (0, 1):
+                for budget in (50, 2):
+                    hard, iters, conv, soft = orc.minsum(Y, budget, prec=32, sign_mode=sm, threads=8)
+                    r = eng.decode(Y, budget, prec=32, sign_mode=sm, want_soft=True)
+                    assert np.array_equal(r['iters'], iters), (qc.row_degrees(), sm, budget, r['iters'], iters)
+                    assert np.array_equal(r['converged'], conv) and np.array_equal(r['hard'], hard)
+                    assert np.array_equal(r['soft'], soft)
+            fast = eng.decode(Y, 50, prec=32, sign_mode=1, want_soft=True)
+            monkeypatch.setenv('LDPC_HIP_NO_PLANES', '1')
+            assert eng.launch_info(prec=32)['lds_bytes'] != 163824
+            slow = eng.decode(Y, 50, prec=32, sign_mode=1, want_soft=True)
+            monkeypatch.delenv('LDPC_HIP_NO_PLANES')
+            for k in ('iters', 'hard_packed', 'soft', 'converged', 'ones'):
+                assert np.array_equal(fast[k], slow[k]), k
+            # the sweep driver on the same kernel, channel values made in the kernel or read from a buffer
+            c1, p1 = eng.eval_awgn([3.2, 3.6], 600, seed=9, per_frame=True, sign_mode=1)
+            monkeypatch.setenv('LDPC_HIP_NO_FUSED_CHANNEL', '1')
+            c2, p2 = eng.eval_awgn([3.2, 3.6], 600, seed=9, per_frame=True, sign_mode=1)
+            monkeypatch.delenv('LDPC_HIP_NO_FUSED_CHANNEL')
+            assert np.array_equal(c1, c2) and np.array_equal(p1, p2)
+    # beyond the limits: 9 extra edges in one block-row, or weight 9 -> the table-driven kernel, same results
+    for qc in (base.with_block(1, 14, hot(7)).with_block(1, 1, hot(6)), base.with_block(0, 4, hot(9))):
+        orc = oracle_mod.Oracle(qc.to_dense())
+        Y = make_llrs(99, 3.5, qc.n, 8)
+        with ldpc_amd.Decoder(qc) as eng:
+            assert eng.launch_info(prec=32)['lds_bytes'] != 163824
+            hard, iters, conv, soft = orc.minsum(Y, 50, prec=32, sign_mode=1, threads=8)
+            r = eng.decode(Y, 50, prec=32, sign_mode=1, want_soft=True)
+            assert np.array_equal(r['iters'], iters) and np.array_equal(r['soft'], soft)

@@ -13,12 +13,14 @@ def main():
     ap.add_argument('--frames', type=int, default=25600)
     ap.add_argument('--budgets', default='0,4')
     ap.add_argument('--snr', type=float, default=1.0)
+    ap.add_argument('--heavy', action='store_true', help='NearEarth with block (0,5) of weight 3 (heavy-circulant kernel)')
     args = ap.parse_args()
     import numpy as np
     import torch
     import ldpc_amd
     from ldpc_amd import codes
-    eng = ldpc_amd.Decoder(codes.near_earth())
+    code = codes.near_earth().with_block(0, 5, [7, 100, 333]) if args.heavy else codes.near_earth()
+    eng = ldpc_amd.Decoder(code)
     dev = torch.device('cuda:0')
     stream = torch.cuda.current_stream()
     eng.set_stream(stream.cuda_stream)
