@@ -958,6 +958,7 @@ struct ldpc_handle {
     float ms_alpha = 1.0f, ms_beta = 0.0f;     // min-sum magnitude correction (ldpc_set_minsum_scaling)
     bool planes_ok = false;
     bool planes_heavy = false;     // some circulant has weight > 2 (extra edges through a global scratch row)
+    int planes_max_w = 0;          // largest circulant weight
     PlanesTables planes{};
     // CSR
     CsrTables csr{};
@@ -1202,43 +1203,58 @@ extern "C" int ldpc_create_qc(int device, int Z, int mb, int nb, const int32_t *
         // message-plane kernel: weights 0..2 directly; up to PLANES_MAXW with the shifts beyond the two
         // lowest as "extra edges", at most PLANES_MAXX of them per block-row
         bool fits = true;
-        int n_extra[2] = {0, 0};
+        int n_extra[2] = {0, 0}, h_max_w = 0;
         for (int b = 0; b < mb; ++b)
             for (int j = 0; j < nb; ++j) {
                 const int w = blk_ptr[b * nb + j + 1] - blk_ptr[b * nb + j];
                 fits = fits && w <= PLANES_MAXW;
+                h_max_w = std::max(h_max_w, w);
                 n_extra[b] += std::max(0, w - 2);
             }
         fits = fits && n_extra[0] <= PLANES_MAXX && n_extra[1] <= PLANES_MAXX;
+        for (int g = 0; g < 2; ++g) {               // heavy block-columns per column group
+            int cnt = 0;
+            for (int j = g; j < nb; j += 2)
+                cnt += (blk_ptr[j + 1] - blk_ptr[j] > 2) || (blk_ptr[nb + j + 1] - blk_ptr[nb + j] > 2);
+            fits = fits && cnt <= PLANES_MAXH;
+        }
         if (fits) {
-            std::vector<int32_t> sh((size_t)mb * nb * 2, 0), colsum((size_t)nb * 2 * (1 + PLANES_MAXW), 0);
+            std::vector<int32_t> sh((size_t)mb * nb * 2, 0);
+            int32_t ent[16][2][8];                   // [block-column][block-row]: the 8 table words (qc_planes.h)
+            uint32_t heavy_cols = 0;
             int nx[2] = {0, 0};
             for (int b = 0; b < mb; ++b)
                 for (int j = 0; j < nb; ++j) {
                     std::vector<int32_t> v(shifts + blk_ptr[b * nb + j], shifts + blk_ptr[b * nb + j + 1]);
                     std::sort(v.begin(), v.end());
-                    int32_t *cs = &colsum[((size_t)j * 2 + b) * (1 + PLANES_MAXW)];
-                    cs[0] = (int32_t)v.size();
-                    for (size_t k = 0; k < v.size(); ++k) {
-                        int src;
+                    const int w = (int)v.size();
+                    const int row0 = (b == 0 ? 0 : n_extra[0]) + nx[b];       // scratch row of this block's first extra edge
+                    ent[j][b][0] = w | ((w > 0 ? v[0] : 511) << 8) | ((w > 1 ? v[1] : 511) << 20) | (b == 0 ? (j >> 1) << 29 : 0);
+                    for (int k = 2; k < PLANES_MAXW; ++k)
+                        ent[j][b][k - 1] = (k < w ? v[k] : 511) | ((k < w ? row0 + k - 2 : (w > 2 ? row0 : 0)) << 16);
+                    ent[j][b][7] = 0;
+                    for (int k = 0; k < w; ++k) {
                         if (k < 2) {
                             sh[((size_t)b * nb + j) * 2 + k] = v[k];
-                            h->planes.edge_mask[b] |= 1u << (2 * j + (int)k);
-                            src = (int)k;
+                            h->planes.edge_mask[b] |= 1u << (2 * j + k);
                         } else {
-                            h->planes.extra[b][nx[b]] = j | (v[k] << 8);
-                            src = 2 + nx[b]++;
-                            h->planes.heavy_cols |= 1u << j;
+                            h->planes.extra[b][nx[b]++] = j | (v[k] << 8);
+                            heavy_cols |= 1u << j;
                         }
-                        cs[1 + (v.size() - 1 - k)] = v[k] | (src << 16);      // descending shift order
                     }
                 }
             h->planes.n_extra[0] = n_extra[0];
             h->planes.n_extra[1] = n_extra[1];
             h->planes.xstride = (uint32_t)(n_extra[0] + n_extra[1]) * PLANES_XROW;
-            if ((rc = upload(h, sh, &h->planes.shifts)) || (rc = upload(h, colsum, &h->planes.colsum))) { ldpc_destroy(h); return rc; }
+            for (int j = 0; j < nb; ++j)
+                if ((heavy_cols >> j) & 1u) {
+                    const int g = j & 1, hh = h->planes.n_heavy[g]++;
+                    memcpy(h->planes.hent[g][hh], ent[j], sizeof(int32_t) * 16);
+                }
+            if ((rc = upload(h, sh, &h->planes.shifts))) { ldpc_destroy(h); return rc; }
             h->planes_ok = true;
-            h->planes_heavy = h->planes.heavy_cols != 0;
+            h->planes_heavy = heavy_cols != 0;
+            h->planes_max_w = h_max_w;
         }
     }
     // the same graph as an edge list, columns ascending inside a row (used by the sum-product kernel)
@@ -1399,15 +1415,21 @@ static bool planes_applies(const ldpc_handle *h, int prec, bool chained, bool sp
 
 static int planes_pick(const ldpc_handle *h, bool spa, Launch *L)
 {
-    if (h->planes_heavy) {
-        L->fn = reinterpret_cast<const void *>(&qc_planes_kernel<511, 8, false, false, true>);
-        L->fn_gen = reinterpret_cast<const void *>(&qc_planes_kernel<511, 8, false, true, true>);
-        L->ws_stride = (size_t)h->planes.xstride * sizeof(float);
+    // LDPC_HIP_FORCE_HEAVY=1 (test hook): the heavy-circulant kernel for a code without heavy circulants
+    const char *force = hook("LDPC_HIP_FORCE_HEAVY");
+    if (h->planes_heavy || (!spa && force && force[0] == '1')) {
+        const bool small = h->planes.n_extra[0] <= PlanesHeavy<1>::MX && h->planes.n_extra[1] <= PlanesHeavy<1>::MX &&
+                           h->planes_max_w <= PlanesHeavy<1>::MW;
+        L->fn = small ? reinterpret_cast<const void *>(&qc_planes_kernel<511, 8, false, false, 1>)
+                      : reinterpret_cast<const void *>(&qc_planes_kernel<511, 8, false, false, 2>);
+        L->fn_gen = small ? reinterpret_cast<const void *>(&qc_planes_kernel<511, 8, false, true, 1>)
+                          : reinterpret_cast<const void *>(&qc_planes_kernel<511, 8, false, true, 2>);
+        L->ws_stride = std::max<size_t>((size_t)h->planes.xstride * sizeof(float), 256);
     } else {
-        L->fn = spa ? reinterpret_cast<const void *>(&qc_planes_kernel<511, 8, true, false, false>)
-                    : reinterpret_cast<const void *>(&qc_planes_kernel<511, 8, false, false, false>);
-        L->fn_gen = spa ? reinterpret_cast<const void *>(&qc_planes_kernel<511, 8, true, true, false>)
-                        : reinterpret_cast<const void *>(&qc_planes_kernel<511, 8, false, true, false>);
+        L->fn = spa ? reinterpret_cast<const void *>(&qc_planes_kernel<511, 8, true, false, 0>)
+                    : reinterpret_cast<const void *>(&qc_planes_kernel<511, 8, false, false, 0>);
+        L->fn_gen = spa ? reinterpret_cast<const void *>(&qc_planes_kernel<511, 8, true, true, 0>)
+                        : reinterpret_cast<const void *>(&qc_planes_kernel<511, 8, false, true, 0>);
     }
     L->planes = true;
     L->block = 2 * PlanesGeom<511, 8>::ZP;
@@ -1475,7 +1497,7 @@ static int slots_pick(const ldpc_handle *h, bool spa, Launch *L)
 
 // Workgroups of `fn` that fit a CU: one attribute call and one occupancy query per
 // (device, kernel, geometry) and process, not per decode call.
-static int blocks_per_cu(int device, const void *fn, int block, size_t lds, int *out)
+static int blocks_per_cu(int device, const void *fn, int block, size_t lds, int *out, bool needs_lds_at_zero = false)
 {
     struct Key { int device; const void *fn; int block; size_t lds; int per_cu; };
     static std::mutex mu;
@@ -1483,6 +1505,13 @@ static int blocks_per_cu(int device, const void *fn, int block, size_t lds, int 
     std::lock_guard<std::mutex> g(mu);
     for (const Key &k : seen)
         if (k.device == device && k.fn == fn && k.block == block && k.lds == lds) { *out = k.per_cu; return 0; }
+    if (needs_lds_at_zero) {
+        // the message-plane kernels address their dynamic LDS from 0: true as long as they have no static LDS
+        hipFuncAttributes at;
+        HIP_TRY(hipFuncGetAttributes(&at, fn));
+        if (at.sharedSizeBytes != 0)
+            return fail(LDPC_E_DEVICE, "kernel built with %zu bytes of static LDS; its dynamic LDS would not start at 0", (size_t)at.sharedSizeBytes);
+    }
     if (lds > 0) HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int per_cu = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, block, lds));
@@ -1514,8 +1543,8 @@ static int select_kernel(ldpc_handle *h, int algo, int prec, bool chained, Launc
             int rc = planes_pick(h, true, L);
             if (rc) return rc;
             L->spa_planes = true;
-            if ((rc = blocks_per_cu(h->device, L->fn, L->block, L->lds, &per_cu)) ||
-                (rc = blocks_per_cu(h->device, L->fn_gen, L->block, L->lds, &per_cu)))
+            if ((rc = blocks_per_cu(h->device, L->fn, L->block, L->lds, &per_cu, true)) ||
+                (rc = blocks_per_cu(h->device, L->fn_gen, L->block, L->lds, &per_cu, true)))
                 return rc;
             L->max_grid = h->n_cu;
             return 0;
@@ -1549,8 +1578,8 @@ static int select_kernel(ldpc_handle *h, int algo, int prec, bool chained, Launc
         else            rc = s64 ? qc_select<double, true>(h, chained, L) : qc_select<double, false>(h, chained, L);
         if (rc) return rc;
         if (L->lds <= h->lds_max) {
-            if ((rc = blocks_per_cu(h->device, L->fn, L->block, L->lds, &per_cu))) return rc;
-            if (L->fn_gen && (rc = blocks_per_cu(h->device, L->fn_gen, L->block, L->lds, &per_cu))) return rc;
+            if ((rc = blocks_per_cu(h->device, L->fn, L->block, L->lds, &per_cu, L->planes))) return rc;
+            if (L->fn_gen && (rc = blocks_per_cu(h->device, L->fn_gen, L->block, L->lds, &per_cu, L->planes))) return rc;
             L->max_grid = h->n_cu * per_cu;
             return 0;
         }

@@ -27,17 +27,23 @@
 // slots no check owns are zeroed once per launch and add +0.
 #pragma once
 
-__device__ __forceinline__ float lds_f32(const unsigned char *smem, uint32_t addr)
+// LDS accesses by byte address.  The kernels of this file have no static LDS, so their dynamic LDS
+// starts at address 0 (the host checks that before it selects them) and a record address IS the
+// LDS address: no base is added, which otherwise costs a vector add per access wherever the
+// compiler does not keep base + address in a register of its own.
+typedef __attribute__((address_space(3))) float lds_float_t;
+typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
+__device__ __forceinline__ float lds_f32(const unsigned char *, uint32_t addr)
 {
-    return *reinterpret_cast<const float *>(smem + addr);
+    return *reinterpret_cast<const lds_float_t *>((uintptr_t)addr);
 }
-__device__ __forceinline__ void lds_put_f32(unsigned char *smem, uint32_t addr, float v)
+__device__ __forceinline__ void lds_put_f32(unsigned char *, uint32_t addr, float v)
 {
-    *reinterpret_cast<float *>(smem + addr) = v;
+    *reinterpret_cast<lds_float_t *>((uintptr_t)addr) = v;
 }
-__device__ __forceinline__ void lds_put_u32(unsigned char *smem, uint32_t addr, uint32_t v)
+__device__ __forceinline__ void lds_put_u32(unsigned char *, uint32_t addr, uint32_t v)
 {
-    *reinterpret_cast<uint32_t *>(smem + addr) = v;
+    *reinterpret_cast<lds_u32_t *>((uintptr_t)addr) = v;
 }
 
 // Channel values of one frame for this thread's CPT columns.  `frame_base` is uniform (scalar
@@ -76,7 +82,16 @@ planes_load_frame(const void *llr, int is_f64, int64_t frame_base, uint32_t firs
 // messages it sent along them last time from the row's compressed state {min1, min2, argmin,
 // signs}; what it sends goes to a per-workgroup scratch row in global memory (the LDS is full),
 // from where the column's owner adds it in the variable pass.
-enum { PLANES_MAXX = 8, PLANES_MAXW = 8, PLANES_XROW = 512 };
+enum { PLANES_MAXX = 8, PLANES_MAXW = 8, PLANES_MAXH = 8, PLANES_XROW = 512 };
+
+// Kernel variants by how heavy the code is (register and code-size budget: the unrolled loops over a
+// row's extra edges and over a heavy block's shifts are sized by these limits, and measured on
+// MI355X the variant with the large limits decodes a weight-3 mutation at 51 Gbit/s, the one with
+// the small limits at 62): HV 0 no heavy circulant, 1 at most 2 extra edges per block-row and
+// weight <= 4, 2 at most PLANES_MAXX extra edges and weight <= PLANES_MAXW.
+template <int HV> struct PlanesHeavy { enum { MX = 1, MW = 2 }; };           // HV 0: unused (array bounds only)
+template <> struct PlanesHeavy<1> { enum { MX = 2, MW = 4 }; };
+template <> struct PlanesHeavy<2> { enum { MX = PLANES_MAXX, MW = PLANES_MAXW }; };
 
 struct PlanesTables {
     uint32_t edge_mask[2];   // [block-row] bit 2j+k set: shift k of circulant (b, j) exists (weight 0, 1 or 2)
@@ -84,9 +99,17 @@ struct PlanesTables {
     // ---- heavy circulants only (HEAVY kernels)
     int n_extra[2];                  // extra edges per row of block-row b
     int32_t extra[2][PLANES_MAXX];   // block-column | shift << 8
-    uint32_t heavy_cols;             // bit j: block-column j holds a heavy circulant
-    const int32_t *colsum;           // [NB][2][1 + PLANES_MAXW]: per (block-column, block-row) the number of shifts, then
-                                     // shift | source << 16 in DESCENDING shift order; source 0, 1: message slot, 2 + x: extra x
+    // Block-columns that hold a heavy circulant, by column group g (thread group g owns block-columns
+    // j = g + 2q): how many, and per column 16 words (by value: kernel arguments are read with scalar
+    // loads, one wide load per column).  Per block-row b, 8 words for block (b, j), whose shifts are
+    // s_0 < s_1 < ... < s_(w-1), s_0 and s_1 on the message slots and s_k, k >= 2, on extra edges:
+    //   word 0: w | s_0 << 8 | s_1 << 20 | q << 29 (q in block-row 0's word only)
+    //   word k-1, k = 2..7: s_k | scratch row of that extra edge << 16
+    // with 511 in place of every shift that does not exist (beyond any position, so it never counts
+    // as "not wrapped") and, for k >= w, the scratch row of some existing extra edge (a valid address;
+    // what is read there is discarded).
+    int n_heavy[2];
+    int32_t hent[2][PLANES_MAXH][16];
     float *xmsg;                     // scratch [workgroup][n_extra[0] + n_extra[1]][PLANES_XROW] extra-edge messages
     uint32_t xstride;                // floats per workgroup in xmsg
 };
@@ -102,7 +125,8 @@ struct PlanesXState {
     float pm1, pm2;                  // the two magnitudes sent
     uint32_t pidx;                   // edge that got pm2: 0..31 slot edges, 32 + x extra x
     uint32_t psign;                  // bit x: the message on extra x was negative
-    float *xrow;                     // scratch of my row: extra x at xrow[x * PLANES_XROW]
+    float *xbase;                    // this workgroup's scratch rows (uniform)
+    uint32_t xoff;                   // my row's element in them: extra x at xbase[xoff + x * PLANES_XROW]
     int X;                           // number of extra edges (uniform)
 };
 
@@ -130,16 +154,16 @@ struct PlanesGeom {
 // last check pass finds every parity satisfied and all its other work is thrown away; when the pass
 // before left no more than PLANES_PRECHECK_T rows unsatisfied, this much cheaper pass is run first
 // and the full one only if it still finds a failing row.  Same stop decision, same iteration count.
-template <int Z, int CPT, bool HEAVY>
+template <int Z, int CPT, int HV>
 __device__ __forceinline__ unsigned long long
 planes_syndrome_only(const unsigned char *smem, const uint32_t (&radr)[CPT * 4], unsigned long long synd0,
                      const PlanesXState &xs)
 {
-    enum { NS = CPT * 4, CHS = 8 };
+    enum { NS = CPT * 4, CHS = 8, HEAVY = HV > 0, MX = PlanesHeavy<HV>::MX };
     unsigned long long synd = synd0;
     if (HEAVY) {
 #pragma unroll
-        for (int x = 0; x < PLANES_MAXX; ++x)
+        for (int x = 0; x < MX; ++x)
             if (x < xs.X) synd ^= __ballot(lds_f32(smem, xs.xadr(x)) > 0.0f);
     }
 #pragma unroll
@@ -156,13 +180,13 @@ planes_syndrome_only(const unsigned char *smem, const uint32_t (&radr)[CPT * 4],
 // Check pass of one row of block-row B.  FIRST: the row's previous messages are all +0
 // (fresh decoder, checkNode.__init__ ldpc.py:121) and are not read.  Returns the lanes
 // whose parity check on the current hard decisions fails.
-template <int Z, int CPT, int B, bool FIRST, bool HEAVY>
+template <int Z, int CPT, int B, bool FIRST, int HV>
 __device__ __forceinline__ unsigned long long
 planes_check_pass(unsigned char *smem, const uint32_t (&radr)[CPT * 4], int D, int sign_mode, int ic,
                   unsigned long long synd0, float alpha, float beta, PlanesXState &xs)
 {
     typedef PlanesGeom<Z, CPT> G;
-    enum { NS = G::NS, CH = PLANES_CH, NCH = NS / CH };
+    enum { NS = G::NS, CH = PLANES_CH, NCH = NS / CH, HEAVY = HV > 0, MX = PlanesHeavy<HV>::MX };
     const float INF = __uint_as_float(0x7f800000u);
     float min1 = INF, min2 = INF;
     uint32_t idx = 0, R = 0;
@@ -171,11 +195,11 @@ planes_check_pass(unsigned char *smem, const uint32_t (&radr)[CPT * 4], int D, i
     if (HEAVY) {
         // The extra edges first (minimum, second minimum and sign product do not depend on the order
         // edges are visited in; equal magnitudes make min2 == min1, so neither does the result of argmin).
-        float px[PLANES_MAXX];
+        float px[MX > 0 ? MX : 1];
 #pragma unroll
-        for (int x = 0; x < PLANES_MAXX; ++x) px[x] = x < xs.X ? lds_f32(smem, xs.xadr(x)) : 0.0f;
+        for (int x = 0; x < MX; ++x) px[x] = x < xs.X ? lds_f32(smem, xs.xadr(x)) : 0.0f;
 #pragma unroll
-        for (int x = 0; x < PLANES_MAXX; ++x) {
+        for (int x = 0; x < MX; ++x) {
             if (x < xs.X) {
                 synd ^= __ballot(px[x] > 0.0f);
                 float v = px[x];
@@ -263,9 +287,10 @@ planes_check_pass(unsigned char *smem, const uint32_t (&radr)[CPT * 4], int D, i
         // extra edges: +-min1, or +-min2 on the arg-min edge (ldpc.py:190-191), to the scratch row
         const uint32_t SX = RX ^ (S ? 0xffffffffu : 0u);
 #pragma unroll
-        for (int x = 0; x < PLANES_MAXX; ++x)
+        for (int x = 0; x < MX; ++x)
             if (x < xs.X)
-                xs.xrow[x * PLANES_XROW] = __uint_as_float((idx == (uint32_t)(NS + x) ? m2 : m1) | (((SX >> x) & 1u) << 31));
+                xs.xbase[opaque(xs.xoff) + (uint32_t)(x * PLANES_XROW)] =
+                    __uint_as_float((idx == (uint32_t)(NS + x) ? m2 : m1) | (((SX >> x) & 1u) << 31));
         xs.pm1 = min1; xs.pm2 = min2; xs.pidx = idx; xs.psign = SX;
     }
     // shift of the arg-min edge, needed after the loop below (idx differs from lane to lane)
@@ -406,10 +431,11 @@ planes_check_pass_spa(unsigned char *smem, const uint32_t (&radr)[CPT * 4], int 
 // carries every per-edge intermediate across the merge in registers.
 // GEN: the kernel makes its own channel values (BPSK/AWGN of the all-zero codeword, awgn.h) instead
 // of reading them: the sweep driver then touches HBM for its per-frame results only.
-template <int Z, int CPT, int B, bool SPA, bool GEN, bool HEAVY>
+template <int Z, int CPT, int B, bool SPA, bool GEN, int HV>
 __device__ __forceinline__ void
 planes_role(unsigned char *smem, const PlanesTables &tb, const DecodeArgs &a)
 {
+    enum { HEAVY = HV > 0, MX = PlanesHeavy<HV>::MX, MW = PlanesHeavy<HV>::MW };
     static_assert(!(HEAVY && SPA), "heavy circulants: min-sum only");
     typedef PlanesGeom<Z, CPT> G;
     enum { MB = G::MB, W = G::W, NB = G::NB, NS = G::NS, N = G::N, ZP = G::ZP, CB = G::CB,
@@ -432,12 +458,14 @@ planes_role(unsigned char *smem, const PlanesTables &tb, const DecodeArgs &a)
     const uint32_t emask = g == 0 ? tb.edge_mask[0] : tb.edge_mask[1];   // existing edges of a row of my block-row
     PlanesXState xs;
     xs.X = HEAVY ? tb.n_extra[B] : 0;
-    xs.pm1 = xs.pm2 = 0.0f; xs.pidx = 0; xs.psign = 0; xs.xrow = nullptr;
+    int n_heavy = HEAVY ? tb.n_heavy[B] : 0;
+    if (HEAVY) asm volatile("" : "+s"(xs.X), "+s"(n_heavy));          // kept in scalar registers, not reloaded from the arguments
+    xs.pm1 = xs.pm2 = 0.0f; xs.pidx = 0; xs.psign = 0; xs.xbase = nullptr; xs.xoff = 0;
     if (HEAVY) {
-        float *mine = tb.xmsg + (size_t)blockIdx.x * tb.xstride;
-        xs.xrow = mine + (size_t)(B == 0 ? 0 : tb.n_extra[0]) * PLANES_XROW + ic;
+        xs.xbase = tb.xmsg + (size_t)blockIdx.x * tb.xstride;
+        xs.xoff = (uint32_t)(B == 0 ? 0 : tb.n_extra[0]) * PLANES_XROW + (uint32_t)ic;
 #pragma unroll
-        for (int x = 0; x < PLANES_MAXX; ++x) {
+        for (int x = 0; x < MX; ++x) {
             const int e = tb.extra[B][x];
             int c = ic + (e >> 8);
             c = c >= Z ? c - Z : c;
@@ -476,59 +504,67 @@ planes_role(unsigned char *smem, const PlanesTables &tb, const DecodeArgs &a)
     }
 
     // HEAVY: columns of a block-column that holds a heavy circulant are summed in full by these two
-    // steps: per block-row all messages of the column's block in ascending check index
-    // (ldpc.py:298-303) -- shifts descending, first the rows c - s that do not wrap (s <= c), then
-    // the wrapped ones.  heavy_fetch reads the messages (slots from LDS, extra edges from the scratch
-    // rows in global memory), heavy_sum adds them and writes the posterior.
+    // steps.  Per block-row the column's messages are added in ascending check index
+    // (ldpc.py:298-303): with the block's shifts ascending and t of them <= c (the position of the
+    // column in its block), the rows c - s of the first t do not wrap and ascend as s descends, then
+    // come the wrapped rows c - s + Z of the others, again as s descends: s_(t-1) .. s_0, s_(w-1) .. s_t.
+    // heavy_fetch reads the messages (slots from LDS, extra edges from the scratch rows in global
+    // memory), heavy_sum adds them -- absent ones as +0, which leaves a sum that started from +0
+    // unchanged bit for bit -- and writes the posterior.  No data-dependent branch, one table load.
     const float *xw = HEAVY ? tb.xmsg + (size_t)blockIdx.x * tb.xstride : nullptr;
-    auto heavy_fetch = [&](int j, float (&m)[2][PLANES_MAXW]) {
-        const uint32_t adr = cadr0 + (uint32_t)(j >> 1) * (MB * Z * CB);
+    auto heavy_fetch = [&](int h, int (&t)[16], float (&m)[2][MW]) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t[k] = tb.hent[B][h][k];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) asm volatile("" : "+s"(t[k]));       // scalar registers from here on, not reloaded
+        const int icl = (int)opaque((uint32_t)ic);
+        const uint32_t adr = (uint32_t)(g * Z + icl) * CB + (uint32_t)((uint32_t)t[0] >> 29) * (MB * Z * CB);
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-            const int32_t *cs = tb.colsum + (j * 2 + b) * (1 + PLANES_MAXW);
-            const int cnt = cs[0];
-            const float *xb = xw + (size_t)(b == 0 ? 0 : tb.n_extra[0]) * PLANES_XROW;
+            m[b][0] = lds_f32(smem, adr + 4u * (uint32_t)(1 + 2 * b));
+            m[b][1] = lds_f32(smem, adr + 4u * (uint32_t)(2 + 2 * b));
+            const int w = t[8 * b] & 0xff;
 #pragma unroll
-            for (int k = 0; k < PLANES_MAXW; ++k) {
-                m[b][k] = 0.0f;
-                if (k < cnt) {
-                    const int e = cs[1 + k], sh = e & 0xffff, src = e >> 16;
-                    int r = ic - sh;
+            for (int k = 2; k < MW; ++k) m[b][k] = 0.0f;
+            if (w > 2) {
+#pragma unroll
+                for (int k = 2; k < MW; ++k) {
+                    const int e = t[8 * b + k - 1];
+                    int r = icl - (e & 0xffff);
                     r = r < 0 ? r + Z : r;
-                    m[b][k] = src < 2 ? lds_f32(smem, adr + 4u * (uint32_t)(1 + 2 * b + src))
-                                      : xb[(src - 2) * PLANES_XROW + r];
+                    const float v = xw[(uint32_t)((e >> 16) * PLANES_XROW + r)];
+                    m[b][k] = k < w ? v : 0.0f;
                 }
             }
         }
     };
-    auto heavy_sum = [&](int j, const float (&m)[2][PLANES_MAXW], const float (&y)[CPT]) {
-        const int q = j >> 1;
+    auto heavy_sum = [&](const int (&t)[16], const float (&m)[2][MW], const float (&y)[CPT]) {
+        const int icl = (int)opaque((uint32_t)ic);
+        const int q = (int)((uint32_t)t[0] >> 29);
         float acc = 0.0f;
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-            const int32_t *cs = tb.colsum + (j * 2 + b) * (1 + PLANES_MAXW);
-            const int cnt = cs[0];
+            const int w0 = t[8 * b];
+            int nw = (((w0 >> 8) & 0x1ff) <= icl) + (((w0 >> 20) & 0x1ff) <= icl);     // shifts that do not wrap at my position
 #pragma unroll
-            for (int k = 0; k < PLANES_MAXW; ++k)
-                if (k < cnt && (cs[1 + k] & 0xffff) <= ic) acc = acc + m[b][k];
+            for (int k = 2; k < MW; ++k) nw += (t[8 * b + k - 1] & 0xffff) <= icl;
 #pragma unroll
-            for (int k = 0; k < PLANES_MAXW; ++k)
-                if (k < cnt && (cs[1 + k] & 0xffff) > ic) acc = acc + m[b][k];
+            for (int k = MW - 1; k >= 0; --k) acc = acc + (k < nw ? m[b][k] : 0.0f);
+#pragma unroll
+            for (int k = MW - 1; k >= 0; --k) acc = acc + (k >= nw ? m[b][k] : 0.0f);
         }
         float yq = y[0];
 #pragma unroll
-        for (int qq = 1; qq < CPT; ++qq) yq = q == qq ? y[qq] : yq;
-        lds_put_f32(smem, cadr0 + (uint32_t)q * (MB * Z * CB), acc + yq);     // channel last, ldpc.py:322
+        for (int qq = 1; qq < CPT; ++qq) {
+            yq = q == qq ? y[qq] : yq;
+            asm volatile("" : "+v"(yq));          // a chain of selects, not a table in scratch memory
+        }
+        lds_put_f32(smem, (uint32_t)(g * Z + icl) * CB + (uint32_t)q * (MB * Z * CB), acc + yq);     // channel last, ldpc.py:322
     };
-    const uint32_t my_heavy = HEAVY ? tb.heavy_cols & (B == 0 ? 0x55555555u : 0xaaaaaaaau) : 0u;   // my block-columns: j = g + 2q
 
     // variable pass (ldpc.py:295-311, 321-323): columns (g + q*MB, ic)
-    auto variable_pass = [&](const float (&y)[CPT]) {
+    auto regular_columns = [&](const float (&y)[CPT]) {
         enum { VB = PLANES_VB };                               // columns per batch: loads first, then sums
-        // HEAVY: the first heavy block-column's messages are requested now and added after the regular
-        // columns, whose work covers the latency of the scratch rows
-        float hm[2][PLANES_MAXW];
-        if (HEAVY && my_heavy) heavy_fetch(__builtin_ctz(my_heavy), hm);
 #pragma unroll
         for (int q0 = 0; q0 < CPT; q0 += VB) {
             set_wave_prio(VB < CPT ? 3 - q0 * 3 / (CPT - VB + (VB == CPT)) : 3);
@@ -554,14 +590,21 @@ planes_role(unsigned char *smem, const PlanesTables &tb, const DecodeArgs &a)
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (HEAVY && my_heavy) {
-            heavy_sum(__builtin_ctz(my_heavy), hm, y);
-            uint32_t todo = my_heavy & (my_heavy - 1);
-            while (todo) {
-                const int j = __builtin_ctz(todo);
-                todo &= todo - 1;
-                heavy_fetch(j, hm);
-                heavy_sum(j, hm, y);
+    };
+    auto variable_pass = [&](const float (&y)[CPT]) {
+        if (!HEAVY) {
+            regular_columns(y);
+        } else {
+            // The first heavy block-column's messages are requested before the regular columns, whose
+            // work covers the latency of the scratch rows, and added after them (what the regular pass
+            // wrote for a heavy column is overwritten here, by the same thread).
+            float hm[2][MW];
+            int ht[16];
+#pragma unroll 1
+            for (int h = 0; h == 0 || h < n_heavy; ++h) {
+                if (h < n_heavy) heavy_fetch(h, ht, hm);
+                if (h == 0) regular_columns(y);
+                if (h < n_heavy) heavy_sum(ht, hm, y);
             }
         }
     };
@@ -700,7 +743,7 @@ planes_role(unsigned char *smem, const PlanesTables &tb, const DecodeArgs &a)
             if (live) {
                 const unsigned long long synd = SPA
                     ? planes_check_pass_spa<Z, CPT, B, true>(smem, radr, D, a.sign_mode, synd0)
-                    : planes_check_pass<Z, CPT, B, true, HEAVY>(smem, radr, D, a.sign_mode, ic, synd0, a.ms_alpha, a.ms_beta, xs);
+                    : planes_check_pass<Z, CPT, B, true, HV>(smem, radr, D, a.sign_mode, ic, synd0, a.ms_alpha, a.ms_beta, xs);
                 // flags[parity]: number of rows whose check fails (bit 20: raised by the syndrome-only pass)
                 if (synd != 0ull && lane == 0) atomicAdd(&flags[0], (int)__popcll(synd));
             }
@@ -719,18 +762,30 @@ planes_role(unsigned char *smem, const PlanesTables &tb, const DecodeArgs &a)
             if (bad == 0 || a.max_iters <= 0) {
                 my_conv = (bad == 0);
             } else {
-                if (tid == 0) flags[1] = 0;
-                if (live) variable_pass(y);
-                lds_barrier();
+                // HEAVY: the variable pass opens the loop body instead of closing it, so that the kernel
+                // holds one copy of it (code size: two CUs share an instruction cache)
+                enum { ROT = HEAVY };
+                if (!ROT) {
+                    if (tid == 0) flags[1] = 0;
+                    if (live) variable_pass(y);
+                    lds_barrier();
+                }
                 TRACE_IT(-1);
                 int unsat = bad;                              // rows left unsatisfied by the check pass before
                 const int precheck_t = a.precheck >= 0 ? a.precheck : (SPA ? PLANES_PRECHECK_T_SPA : PLANES_PRECHECK_T);   // 0: never (unsat > 0 here)
                 for (int it = 1;; ++it) {
                     const int par = it & 1;
+                    if (ROT) {
+                        if (tid == 0) flags[par] = 0;
+                        if (live) variable_pass(y);
+                        TRACE_IT(2);
+                        lds_barrier();
+                        TRACE_IT(3);
+                    }
                     if (unsat <= precheck_t) {
                         ++n_synd;
                         if (live) {
-                            const unsigned long long synd = planes_syndrome_only<Z, CPT, HEAVY>(smem, radr, synd0, xs);
+                            const unsigned long long synd = planes_syndrome_only<Z, CPT, HV>(smem, radr, synd0, xs);
                             if (synd != 0ull && lane == 0) flags[par] = 1 << 20;
                         }
                         lds_barrier();
@@ -743,7 +798,7 @@ planes_role(unsigned char *smem, const PlanesTables &tb, const DecodeArgs &a)
                     if (live) {
                         const unsigned long long synd = SPA
                             ? planes_check_pass_spa<Z, CPT, B, false>(smem, radr, D, a.sign_mode, synd0)
-                            : planes_check_pass<Z, CPT, B, false, HEAVY>(smem, radr, D, a.sign_mode, ic, synd0, a.ms_alpha, a.ms_beta, xs);
+                            : planes_check_pass<Z, CPT, B, false, HV>(smem, radr, D, a.sign_mode, ic, synd0, a.ms_alpha, a.ms_beta, xs);
                         if (synd != 0ull && lane == 0) atomicAdd(&flags[par], (int)__popcll(synd));
                     }
                     ++n_full;
@@ -758,11 +813,13 @@ planes_role(unsigned char *smem, const PlanesTables &tb, const DecodeArgs &a)
                         my_conv = (bad2 == 0);
                         break;
                     }
-                    if (tid == 0) flags[par ^ 1] = 0;
-                    if (live) variable_pass(y);
-                    TRACE_IT(2);
-                    lds_barrier();
-                    TRACE_IT(3);
+                    if (!ROT) {
+                        if (tid == 0) flags[par ^ 1] = 0;
+                        if (live) variable_pass(y);
+                        TRACE_IT(2);
+                        lds_barrier();
+                        TRACE_IT(3);
+                    }
                 }
             }
         }
@@ -843,13 +900,13 @@ planes_role(unsigned char *smem, const PlanesTables &tb, const DecodeArgs &a)
 #endif
 }
 
-template <int Z, int CPT, bool SPA, bool GEN, bool HEAVY>
+template <int Z, int CPT, bool SPA, bool GEN, int HV>
 __global__ void __launch_bounds__(1024)
 qc_planes_kernel(const PlanesTables tb, const DecodeArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (__builtin_amdgcn_readfirstlane(threadIdx.x / PlanesGeom<Z, CPT>::ZP) == 0)
-        planes_role<Z, CPT, 0, SPA, GEN, HEAVY>(smem, tb, a);
+        planes_role<Z, CPT, 0, SPA, GEN, HV>(smem, tb, a);
     else
-        planes_role<Z, CPT, 1, SPA, GEN, HEAVY>(smem, tb, a);
+        planes_role<Z, CPT, 1, SPA, GEN, HV>(smem, tb, a);
 }
