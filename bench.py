@@ -59,6 +59,184 @@ def cpu_baseline(llr_dev, n_frames, n_threads, slice_frames=16384):
                 mean_iters=float(iters.mean())), iters
 
 
+def wilson(k, n, z=1.96):
+    """95 % Wilson score interval of a proportion k / n."""
+    if n == 0:
+        return [0.0, 1.0]
+    p = k / n
+    d = 1 + z * z / n
+    mid = (p + z * z / (2 * n)) / d
+    half = z * ((p * (1 - p) + z * z / (4 * n)) / n) ** 0.5 / d
+    return [max(mid - half, 0.0), min(mid + half, 1.0)]
+
+
+def cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return None
+
+
+def committed_counters(prec, frames, spa):
+    """HBM bytes per launch and busy fractions from the committed counter passes (rocprofv3 --pmc cannot
+    run inside this process), with the file and the commit they were taken on so that a stale constant
+    shows; all None for a configuration that was not profiled."""
+    prof = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
+    if spa or not os.path.exists(prof):
+        return None, None, None
+    try:
+        pj = json.load(open(prof))
+        e = pj.get(f'prec{prec}_frames{frames}')
+        if not e:
+            return None, None, None
+        onchip = {k: e[k] for k in ('valu_busy_frac', 'lds_busy_frac') if k in e}
+        src = {'file': 'profiles/hbm_traffic.json', 'summary': e.get('source'), 'library_commit': e.get('library_commit'),
+               'taken': e.get('taken'), 'measured_in_this_run': False}
+        return e['hbm_bytes_per_launch'], onchip, src
+    except Exception:
+        return None, None, None
+
+
+def lds_roofline(eng, step, F, mean_iters, k_ms, dev):
+    """On-chip roofline of the float32 min-sum kernel, from pass counts measured in one extra launch
+    (the kernel counts its full and its syndrome-only check passes): LDS bytes the passes must move
+    against (a) the nominal 128 B/clk/CU and (b) the time the same bytes take at the rates measured
+    for the instructions that move them (tools/microbench/peaks.hip)."""
+    import torch
+    E, N, M = 32704, N_CODE, 1022
+    cnt = torch.zeros(2, dtype=torch.int64, device=dev)
+    eng.set_pass_counters(cnt)
+    step()
+    torch.cuda.synchronize()
+    eng.set_pass_counters(None)
+    n_full, n_synd = (float(x) / F for x in cnt.cpu().tolist())
+    # per frame: one first check pass (no previous messages to read), n_full - 1 later ones, n_synd syndrome-only
+    # passes, one variable pass per iteration
+    by_instr = {
+        'ds_read2_b32': (n_full - 1.0) * 8 * E,                      # posterior + previous message per edge
+        'ds_read_b32': 1.0 * 4 * E + n_synd * 4 * E + mean_iters * 4 * E + n_full * 4 * M,   # first pass, syndrome-only, variable-pass messages, arg-min shift
+        'ds_write_b32': n_full * (4 * E + 4 * M) + mean_iters * 4 * N,                     # messages + arg-min patch, posteriors
+    }
+    total = sum(by_instr.values())
+    t = k_ms * 1e-3
+    nominal = 256 * 128 * 2.4e9
+    rate = total * F / t
+    out = {'bound': 'lds', 'achieved': rate / 1e12, 'peak': nominal / 1e12, 'unit': 'TB/s', 'frac': rate / nominal,
+           'lds_bytes_per_frame': total, 'check_passes_per_frame': n_full, 'syndrome_only_passes_per_frame': n_synd,
+           'variable_passes_per_frame': mean_iters, 'measured_in_this_run': True,
+           'bytes_per_pass': {'first_check': 8 * E + 8 * M, 'check': 12 * E + 8 * M, 'syndrome_only': 4 * E, 'variable': 4 * E + 4 * N}}
+    peaks = os.path.join(ROOT, 'profiles', 'r01_onchip_peaks.json')
+    if os.path.exists(peaks):
+        try:
+            pk = {e['access']: e['bytes_per_clk_per_cu'] for e in json.load(open(peaks))['lds']}
+            rates = {'ds_read2_b32': pk['ds_read2_b32 stride 20'], 'ds_read_b32': pk['ds_read_b32 stride 20'],
+                     'ds_write_b32': pk['ds_write_b32 stride 20']}
+            clk = sum(by_instr[k] / rates[k] for k in by_instr)          # LDS clocks per frame on one CU at the measured rates
+            floor_s = clk * F / 256 / 2.4e9
+            out['measured_mix'] = {'rates_bytes_per_clk_per_cu': rates, 'source': 'profiles/r01_onchip_peaks.json',
+                                   'lds_time_floor_ms': floor_s * 1e3, 'frac': floor_s / t,
+                                   'bytes_by_instruction_per_frame': by_instr}
+        except Exception:
+            pass
+    return out
+
+
+def fixed_iterations(eng, llr, F, args, algo, spa, hard, iters, conv, ones, stream, rank):
+    """Forced 50 iterations (no frame converges at 0 dB): the per-iteration rate without early stop."""
+    import torch
+    Ff = min(F, 65536)
+    eng.channel_awgn_device(llr[:Ff], Ff, 0.0, seed=args.seed + 1, first_frame=0)
+    ms = None
+    for _ in range(2):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        eng.decode_device(llr, Ff, args.max_iters, prec=args.prec, algo=algo, llr_scale=4.0 if spa else 1.0,
+                          d_hard=hard, d_iters=iters, d_conv=conv, d_ones=ones)
+        e1.record(stream)
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1)
+    out = {'info_gbps': K_INFO * Ff / (ms * 1e-3) / 1e9, 'frames': Ff, 'snr_db': 0.0,
+           'mean_iters': float(iters[:Ff].float().mean()), 'kernel_ms': ms}
+    eng.channel_awgn_device(llr[:Ff], Ff, args.snr, seed=args.seed, first_frame=rank * F)   # restore the batch
+    torch.cuda.synchronize()
+    return out
+
+
+def secondary(eng, llr, F, args, hard, iters, conv, ones, stream, dev):
+    """Other configurations of the same path, one warm-up and one timed launch each, after the headline's
+    timed region (not part of `value`): info Gbit/s from events on the launch stream, or wall time for the
+    sweep driver (which synchronises itself)."""
+    import torch
+    import ldpc_amd
+    from ldpc_amd import codes
+    out = []
+
+    def timed(name, e, buf, n_frames, k_info, **kw):
+        ms = None
+        for _ in range(2):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            e.decode_device(buf, n_frames, args.max_iters, d_hard=hard, d_iters=iters, d_conv=conv, d_ones=ones, **kw)
+            e1.record(stream)
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1)
+        it = iters[:n_frames]
+        out.append({'case': name, 'frames': n_frames, 'kernel_ms': ms, 'info_gbps': k_info * n_frames / (ms * 1e-3) / 1e9,
+                    'mean_iters': float(it.float().mean()), 'fer': float((ones[:n_frames] != 0).float().mean()),
+                    'launch': e.launch_info(algo=kw.get('algo', 0), prec=kw.get('prec', 32))})
+
+    # the headline batch in float64 (the arithmetic that is bit-identical to the reference's CPU decoder) and sum-product
+    timed('NearEarth min-sum float64, %.1f dB' % args.snr, eng, llr, F, K_INFO, prec=64)
+    timed('NearEarth sum-product float32, %.1f dB' % args.snr, eng, llr, F, K_INFO, prec=32, algo=ldpc_amd.ALGO_SUMPRODUCT,
+          llr_scale=4.0 * 10 ** (args.snr / 10))
+    out.append(dict(case='NearEarth min-sum float32, all 50 iterations forced (0 dB)',
+                    **fixed_iterations(eng, llr, F, args, ldpc_amd.ALGO_MINSUM, False, hard, iters, conv, ones, stream, 0)))
+    # a whole sweep point: channel + decode + counters (ldpc_eval_awgn), wall time of the call
+    ws = None
+    for _ in range(2):
+        t0 = time.perf_counter()
+        cnt, _ = eng.eval_awgn([args.snr], F, seed=args.seed + 7, prec=32)
+        ws = time.perf_counter() - t0
+    out.append({'case': 'sweep point: channel + decode + counters in one call, NearEarth min-sum float32, %.1f dB' % args.snr,
+                'frames': F, 'wall_ms': ws * 1e3, 'info_gbps': K_INFO * F / ws / 1e9, 'mean_iters': float(cnt[0, 3]) / F,
+                'fer': float(cnt[0, 1]) / F})
+    # gym-style mutations of NearEarth (ldpc_env.py:293-317): one circulant of weight 3, one of weight 7
+    base = codes.near_earth()
+    Fm = min(F, 200000)
+    for name, code in (('NearEarth with block (0,5) of weight 3, min-sum float32', base.with_block(0, 5, [7, 100, 333])),
+                       ('NearEarth with block (1,9) of weight 7, min-sum float32', base.with_block(1, 9, [3, 77, 150, 222, 301, 404, 500]))):
+        with ldpc_amd.Decoder(code, device=eng.device) as e2:
+            e2.set_stream(stream.cuda_stream)
+            timed(name + ', corrected sign rule, %.1f dB' % args.snr, e2, llr, Fm, K_INFO, prec=32, sign_mode=ldpc_amd.SIGN_CORRECTED)
+    # 802.11n n = 1944 codes (corrected sign rule: the reference's rule does not decode odd check degrees)
+    for rate, qc in codes.wifi_1944_all().items():
+        with ldpc_amd.Decoder(qc, device=eng.device) as e2:
+            e2.set_stream(stream.cuda_stream)
+            Fw = min(2_000_000, (llr.numel() // e2.n))
+            buf = llr.view(-1)[:Fw * e2.n].view(Fw, e2.n)
+            snr = {'1/2': 2.0, '2/3': 3.0, '3/4': 3.5, '5/6': 4.0}[rate]
+            e2.channel_awgn_device(buf, Fw, snr, seed=args.seed + 3)
+            hw = hard.view(-1)[:Fw * e2.nbytes].view(Fw, e2.nbytes) if hard.numel() >= Fw * e2.nbytes else None
+            ms = None
+            for _ in range(2):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                e2.decode_device(buf, Fw, args.max_iters, prec=32, sign_mode=ldpc_amd.SIGN_CORRECTED, d_hard=hw)
+                e1.record(stream)
+                torch.cuda.synchronize()
+                ms = e0.elapsed_time(e1)
+            k_info = e2.n - e2.m
+            out.append({'case': '802.11n n=1944 rate %s min-sum float32, corrected sign rule, %.1f dB' % (rate, snr), 'frames': Fw,
+                        'kernel_ms': ms, 'info_gbps': k_info * Fw / (ms * 1e-3) / 1e9, 'launch': e2.launch_info(prec=32)})
+    # the headline batch back in place
+    eng.channel_awgn_device(llr, F, args.snr, seed=args.seed, first_frame=0)
+    torch.cuda.synchronize()
+    return out
+
+
 def launch_ranks(n_ranks, script_argv, timeout=None):
     """`python bench.py --gpus N` outside a launcher: start N ranks of `script_argv` under
     torch.distributed.run (one process per GPU, the reference's device fan-out,
@@ -180,9 +358,10 @@ def main():
                           d_hard=hard, d_iters=iters, d_conv=conv, d_ones=ones)
 
     def counters():
+        o64 = ones.to(torch.int64)
         c = torch.stack([torch.tensor(F, device=dev, dtype=torch.int64),
-                         (ones != 0).sum(), ones.sum(dtype=torch.int64), iters.sum(dtype=torch.int64),
-                         unc.sum(dtype=torch.int64), (conv == 0).sum()])
+                         (ones != 0).sum(), o64.sum(), iters.sum(dtype=torch.int64),
+                         unc.sum(dtype=torch.int64), (conv == 0).sum(), (o64 * o64).sum()])
         if use_dist:
             if backend == 'nccl':
                 dist.all_reduce(c)      # the path's only exchange: error counters (RCCL)
@@ -225,49 +404,22 @@ def main():
         k_ms = float(np.mean(kernel_ms))
         achieved = BYTES_PER_FRAME * F / (k_ms * 1e-3) / 1e9
         info = eng.launch_info(algo=algo, prec=args.prec)
-        # HBM bytes per launch from the committed counter passes (rocprofv3 --pmc cannot run
-        # inside this process); null for a configuration that was not profiled
-        traffic, onchip = None, None
-        prof = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
-        if os.path.exists(prof):
-            try:
-                pj = json.load(open(prof))
-                key = f'prec{args.prec}_frames{F}'
-                if key in pj:
-                    traffic = pj[key]['hbm_bytes_per_launch']
-                    onchip = {k: pj[key][k] for k in ('valu_busy_frac', 'lds_busy_frac') if k in pj[key]}
-            except Exception:
-                traffic, onchip = None, None
-        kernel = 'qc_planes_kernel<511, 8, false>' if args.prec == 32 else 'qc_regular_kernel<double, 2, 2, 8, 1, false>'
-        if spa:
-            kernel = 'qc_planes_kernel<511, 8, true>' if args.prec == 32 else 'csr_spa_kernel<double>'
-            traffic, onchip = None, None
-        # on-chip roofline of the float32 min-sum kernel: LDS bytes it must move per frame-iteration
-        # (16 B per edge + 4 B per column + 8 B per row) against 256 CUs x 128 B/clk x 2.4 GHz
         mean_iters = float(c[3]) / total_frames
+        kernel = 'qc_planes_kernel<511, 8, false, false, 0>' if args.prec == 32 else 'qc_regular_kernel<double, 2, 2, 8, 1, false>'
+        if spa:
+            kernel = 'qc_planes_kernel<511, 8, true, false, 0>' if args.prec == 32 else 'csr_spa_kernel<double>'
+        traffic, onchip, traffic_source = committed_counters(args.prec, F, spa)
         lds = None
         if args.prec == 32 and not spa:
-            lds_bytes_iter = 16 * 32704 + 4 * N_CODE + 8 * 1022
-            # one check pass more than iterations per frame (the pass that finds the syndrome zero / the budget spent)
-            lds_rate = lds_bytes_iter * (mean_iters + 0.75) * F / (k_ms * 1e-3) / 1e12
-            lds = {'bound': 'lds', 'achieved': lds_rate, 'peak': 256 * 128 * 2.4e9 / 1e12, 'unit': 'TB/s',
-                   'frac': lds_rate / (256 * 128 * 2.4e9 / 1e12), 'bytes_per_frame_iteration': lds_bytes_iter}
+            lds = lds_roofline(eng, step, F, mean_iters, k_ms, dev)
         fixed = None
         if args.fixed50:
-            # forced 50 iterations (no frame converges at 0 dB): the per-iteration rate without early stop
-            Ff = min(F, 65536)
-            eng.channel_awgn_device(llr[:Ff], Ff, 0.0, seed=args.seed + 1, first_frame=0)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(stream)
-            eng.decode_device(llr, Ff, args.max_iters, prec=args.prec, algo=algo, llr_scale=4.0 if spa else 1.0,
-                              d_hard=hard, d_iters=iters, d_conv=conv, d_ones=ones)
-            e1.record(stream)
-            torch.cuda.synchronize()
-            fixed_ms = e0.elapsed_time(e1)
-            fixed = {'info_gbps': K_INFO * Ff / (fixed_ms * 1e-3) / 1e9, 'frames': Ff, 'snr_db': 0.0,
-                     'mean_iters': float(iters[:Ff].float().mean()), 'kernel_ms': fixed_ms}
-            eng.channel_awgn_device(llr[:Ff], Ff, args.snr, seed=args.seed, first_frame=rank * F)   # restore the batch
-            torch.cuda.synchronize()
+            fixed = fixed_iterations(eng, llr, F, args, algo, spa, hard, iters, conv, ones, stream, rank)
+        fer, ber = float(c[1]) / total_frames, float(c[2]) / (total_frames * N_CODE)
+        # 95 % intervals: Wilson for the frame error rate; for the bit error rate the frame is the sampling unit
+        # (bit errors come in bursts inside failed frames), so the spread of errors per frame sets the width
+        var_frame = max(float(c[6]) / total_frames - (float(c[2]) / total_frames) ** 2, 0.0)
+        ber_half = 1.96 * (var_frame / total_frames) ** 0.5 / N_CODE
         out = {
             'metric': 'decoded info Gbit/s, NearEarth (8176,7154) %s @50 iters' % ('sum-product' if spa else 'min-sum'),
             'value': value, 'unit': 'Gbit/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -280,17 +432,19 @@ def main():
                        'frames_per_gpu': F, 'snr_db': args.snr, 'max_iters': args.max_iters,
                        'parallelism': f'frames sharded over {world} GPU(s), counters all-reduced'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_source,
                          'kernel': kernel, 'kernel_ms': k_ms,
                          'algorithmic_bytes_per_frame': BYTES_PER_FRAME, 'onchip': onchip,
                          'note': 'message passing runs out of LDS and registers; HBM carries only LLR-in and '
                                  'results-out, so the HBM fraction is small by design.  The kernel is bound by '
-                                 'vector-instruction issue and LDS bandwidth (onchip: busy fractions from the '
-                                 'committed counter passes)'},
+                                 'vector-instruction issue and LDS bandwidth (roofline_lds: measured in this run; '
+                                 'traffic / onchip: from the committed counter passes named in traffic_source, '
+                                 'not measured in this run)'},
             'roofline_lds': lds,
             'fixed_iterations': fixed,
             'stats': {'frames': total_frames, 'mean_iters': mean_iters,
-                      'fer': float(c[1]) / total_frames, 'ber': float(c[2]) / (total_frames * N_CODE),
+                      'fer': fer, 'fer_ci95': wilson(int(c[1]), total_frames),
+                      'ber': ber, 'ber_ci95': [max(ber - ber_half, 0.0), ber + ber_half],
                       'uncoded_ber': float(c[4]) / (total_frames * N_CODE),
                       'not_codeword': int(c[5])},
             'launch': info,
@@ -298,10 +452,14 @@ def main():
             'frames_per_s': total_frames * args.steps / elapsed,
             'channel_fill_s': t_channel,
         }
+        if world == 1 and not args.no_secondary and not spa and args.prec == 32:
+            out['secondary'] = secondary(eng, llr, F, args, hard, iters, conv, ones, stream, dev)
         if not args.no_cpu and world == 1 and not spa:
             ncpu = min(16, os.cpu_count() or 1)
             m = min(args.cpu_frames, F)
             base, it_cpu = cpu_baseline(llr, m, ncpu)
+            base.update(cpu_model=cpu_model(), os_cpu_count=os.cpu_count(),
+                        cores_note='OpenMP threads used = min(16, os.cpu_count()): the GPU box gives one job 16 host threads')
             out['cpu_baseline'] = base
             if args.prec == 64:
                 out['cpu_gpu_iters_equal'] = bool(np.array_equal(it_cpu, iters[:m].cpu().numpy()))

@@ -90,6 +90,12 @@ int ldpc_get_dims(const ldpc_handle *h, int *m, int *n, int *edges);
  * decoder variant).  Needs alpha > 0, beta >= 0. */
 int ldpc_set_minsum_scaling(ldpc_handle *h, float alpha, float beta);
 
+/* Measurement aid, no counterpart in the reference: d_counts points to two uint64 in device memory
+ * (or NULL to switch off, the default).  Every later float32 decode of the message-plane kernels adds
+ * to them the number of full check passes (d_counts[0]) and of syndrome-only passes (d_counts[1]) its
+ * workgroups ran -- what the on-chip roofline of bench.py is computed from.  The caller zeroes them. */
+int ldpc_set_pass_counters(ldpc_handle *h, uint64_t *d_counts);
+
 /* Make the handle launch on an existing HIP stream: hip_stream is a hipStream_t
  * passed as void* (NULL is the legacy default stream, which is a valid choice);
  * use_own != 0 ignores hip_stream and goes back to the stream the handle

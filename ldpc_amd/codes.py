@@ -32,6 +32,48 @@ WIFI_1944_R56 = (
 )
 
 
+# The other three n = 1944, Z = 81 prototype matrices of IEEE 802.11n-2009 (Annex R; the text's
+# Table R.3): rates 1/2, 2/3 and 3/4.  NOT in the reference (it carries rate 5/6 only), so nothing
+# of the reference pins them: they are restated from the standard, and tests/test_wifi_rates.py checks
+# what can be checked without it (the standard's dual-diagonal parity structure, full rank, girth >= 6,
+# decoding behaviour).
+_ = -1
+WIFI_1944_R12 = (
+    (57, _, _, _, 50, _, 11, _, 50, _, 79, _, 1, 0, _, _, _, _, _, _, _, _, _, _),
+    (3, _, 28, _, 0, _, _, _, 55, 7, _, _, _, 0, 0, _, _, _, _, _, _, _, _, _),
+    (30, _, _, _, 24, 37, _, _, 56, 14, _, _, _, _, 0, 0, _, _, _, _, _, _, _, _),
+    (62, 53, _, _, 53, _, _, 3, 35, _, _, _, _, _, _, 0, 0, _, _, _, _, _, _, _),
+    (40, _, _, 20, 66, _, _, 22, 28, _, _, _, _, _, _, _, 0, 0, _, _, _, _, _, _),
+    (0, _, _, _, 8, _, 42, _, 50, _, _, 8, _, _, _, _, _, 0, 0, _, _, _, _, _),
+    (69, 79, 79, _, _, _, 56, _, 52, _, _, _, 0, _, _, _, _, _, 0, 0, _, _, _, _),
+    (65, _, _, _, 38, 57, _, _, 72, _, 27, _, _, _, _, _, _, _, _, 0, 0, _, _, _),
+    (64, _, _, _, 14, 52, _, _, 30, _, _, 32, _, _, _, _, _, _, _, _, 0, 0, _, _),
+    (_, 45, _, 70, 0, _, _, _, 77, 9, _, _, _, _, _, _, _, _, _, _, _, 0, 0, _),
+    (2, 56, _, 57, 35, _, _, _, _, _, 12, _, _, _, _, _, _, _, _, _, _, _, 0, 0),
+    (24, _, 61, _, 60, _, _, 27, 51, _, _, 16, 1, _, _, _, _, _, _, _, _, _, _, 0),
+)
+WIFI_1944_R23 = (
+    (61, 75, 4, 63, 56, _, _, _, _, _, _, 8, _, 2, 17, 25, 1, 0, _, _, _, _, _, _),
+    (56, 74, 77, 20, _, _, _, 64, 24, 4, 67, _, 7, _, _, _, _, 0, 0, _, _, _, _, _),
+    (28, 21, 68, 10, 7, 14, 65, _, _, _, 23, _, _, _, 75, _, _, _, 0, 0, _, _, _, _),
+    (48, 38, 43, 78, 76, _, _, _, _, 5, 36, _, 15, 72, _, _, _, _, _, 0, 0, _, _, _),
+    (40, 2, 53, 25, _, 52, 62, _, 20, _, _, 44, _, _, _, _, 0, _, _, _, 0, 0, _, _),
+    (69, 23, 64, 10, 22, _, 21, _, _, _, _, _, 68, 23, 29, _, _, _, _, _, _, 0, 0, _),
+    (12, 0, 68, 20, 55, 61, _, 40, _, _, _, 52, _, _, _, 44, _, _, _, _, _, _, 0, 0),
+    (58, 8, 34, 64, 78, _, _, 11, 78, 24, _, _, _, _, _, 58, 1, _, _, _, _, _, _, 0),
+)
+WIFI_1944_R34 = (
+    (48, 29, 28, 39, 9, 61, _, _, _, 63, 45, 80, _, _, _, 37, 32, 22, 1, 0, _, _, _, _),
+    (4, 49, 42, 48, 11, 30, _, _, _, 49, 17, 41, 37, 15, _, 54, _, _, _, 0, 0, _, _, _),
+    (35, 76, 78, 51, 37, 35, 21, _, 17, 64, _, _, _, 59, 7, _, _, 32, _, _, 0, 0, _, _),
+    (9, 65, 44, 9, 54, 56, 73, 34, 42, _, _, _, 35, _, _, _, 46, 39, 0, _, _, 0, 0, _),
+    (3, 62, 7, 80, 68, 26, _, 80, 55, _, 36, _, 26, _, 9, _, 72, _, _, _, _, _, 0, 0),
+    (26, 75, 33, 21, 69, 59, 3, 38, _, _, _, 35, _, 62, 36, 26, _, _, 1, _, _, _, _, 0),
+)
+del _
+WIFI_1944_TABLES = {'1/2': WIFI_1944_R12, '2/3': WIFI_1944_R23, '3/4': WIFI_1944_R34, '5/6': WIFI_1944_R56}
+
+
 class QCCode:
     """Quasi-cyclic code as per-block shift lists.
 
@@ -104,6 +146,15 @@ def near_earth_zeroed(b, j):
 
 def wifi_1944_r56():
     return QCCode(WIFI_1944_Z, [[() if s < 0 else (s,) for s in row] for row in WIFI_1944_R56])
+
+
+def wifi_1944(rate):
+    """802.11n n = 1944 code of rate '1/2', '2/3', '3/4' or '5/6' (only 5/6 is in the reference)."""
+    return QCCode(WIFI_1944_Z, [[() if s < 0 else (s,) for s in row] for row in WIFI_1944_TABLES[rate]])
+
+
+def wifi_1944_all():
+    return {rate: wifi_1944(rate) for rate in ('1/2', '2/3', '3/4', '5/6')}
 
 
 def dense_to_qc(H, Z):

@@ -2,12 +2,12 @@
 // several frames per workgroup, every check-to-variable message explicit in LDS.
 // Included by ldpc_hip.hip.
 //
-// Works for any parity-check matrix with column degree <= 4, row degree <= DC and at most
-// 1024 rows per workgroup (frames per workgroup F = as many as threads and LDS allow).
+// Works for any parity-check matrix with column degree <= DV (4, 8 or 12), row degree <= DC and at
+// most 1024 rows per workgroup (frames per workgroup F = as many as threads and LDS allow).
 //   thread t  -> check row  t mod m  of frame  t / m  of the workgroup's block of F frames
 //               (its edge addresses live in registers for the whole launch), and
 //            -> columns t, t + NT, t + 2 NT, ... of the F*n columns of the block.
-//   LDS       -> one 20-byte record per column { posterior, message slot 0..3 }, slot k holding
+//   LDS       -> one record of 1 + DV words per column { posterior, message slot 0..DV-1 }, slot k holding
 //               the message of the column's k-th check in ascending check index, so the variable
 //               update is the plain ordered sum of ldpc.py:298-303 (unused slots stay +0);
 //               per-frame stop flags and counters; one dummy record.  The channel values of a
@@ -33,13 +33,16 @@ struct SlotTables {
     const int32_t *row_ptr;    // [m+1]
     const int32_t *col_idx;    // [E] ascending inside a row
     const int32_t *edge_slot;  // [E] rank of the edge's row among the rows of its column
+    const int32_t *col_ptr;    // [n+1] (column degrees)
 };
 
 struct SlotGeom {
-    enum { CB = 20, YMAX = 8 };
+    enum { YMAX = 8 };
+    uint32_t CB;               // bytes per column record: 4 * (1 + DV)
     uint32_t y_off, flag_off, cont_off, claim_off, ones_off, wcnt_off, want_off, pre_off, plan_off, dummy_off, bytes;
-    __host__ __device__ SlotGeom(int n, int F)
+    __host__ __device__ SlotGeom(int n, int F, int DV)
     {
+        CB = 4u * (1u + (uint32_t)DV);
         const uint32_t cols = (uint32_t)n * (uint32_t)F;
         y_off = cols * CB;                    // (end of the records)
         flag_off = y_off;                     // [2][F] "syndrome of frame non-zero"
@@ -71,16 +74,16 @@ __device__ __forceinline__ void slot_count_failures(unsigned long long synd, int
 
 // SPA = true: sum-product check rule (stated with csr_spa_kernel; phi from planes_phi) in
 // place of min-sum; everything else is shared.
-template <int DC, bool SPA>
+template <int DC, int DV, bool SPA>
 __global__ void __launch_bounds__(1024)
 slot_minsum_kernel(const SlotTables tb, const DecodeArgs a)
 {
-    enum { CB = SlotGeom::CB, YMAX = SlotGeom::YMAX, CH = 4, NCH = DC / CH,
+    enum { CB = 4 * (1 + DV), YMAX = SlotGeom::YMAX, CH = 4, NCH = DC / CH,
            SLOT_PRECHECK_T = SPA ? SLOT_PRECHECK_T_SPA : SLOT_PRECHECK_T_MINSUM };
-    static_assert(DC % CH == 0 && DC <= 32, "row degree bound");
+    static_assert(DC % CH == 0 && DC <= 32 && DV <= 15, "degree bounds");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int m = tb.m, n = tb.n, F = tb.F;
-    const SlotGeom G(n, F);
+    const SlotGeom G(n, F, DV);
     const int NT = blockDim.x;
     const int tid = threadIdx.x;
     const int cols = F * n;
@@ -119,7 +122,19 @@ slot_minsum_kernel(const SlotTables tb, const DecodeArgs a)
         const int cg = k * NT + tid;
         if (cg < cols) colf |= (unsigned long long)(cg / n) << (8 * k);
     }
-    if (tid < 5) lds_put_u32(smem, G.dummy_off + 4u * tid, tid == 0 ? 0x7f800000u : 0u);
+    // degree of each of my columns, four bits per column (DV > 4: the variable pass reads only the slots in use)
+    uint32_t cdeg = 0;
+    if (DV > 4) {
+#pragma unroll
+        for (int k = 0; k < YMAX; ++k) {
+            const int cg = k * NT + tid;
+            if (cg < cols) {
+                const int c = cg % n;
+                cdeg |= (uint32_t)(tb.col_ptr[c + 1] - tb.col_ptr[c]) << (4 * k);
+            }
+        }
+    }
+    if (tid < 1 + DV) lds_put_u32(smem, G.dummy_off + 4u * tid, tid == 0 ? 0x7f800000u : 0u);
 
     const int64_t n_fblocks = (a.n_frames + F - 1) / F;
     // channel values of my columns, prefetched one block of frames ahead (float32 inputs)
@@ -159,7 +174,7 @@ slot_minsum_kernel(const SlotTables tb, const DecodeArgs a)
                 const uint32_t rec = (uint32_t)cg * CB;
                 lds_put_f32(smem, rec, ycur[k]);
 #pragma unroll
-                for (int sl = 1; sl <= 4; ++sl) lds_put_f32(smem, rec + 4u * sl, 0.0f);
+                for (int sl = 1; sl <= DV; ++sl) lds_put_f32(smem, rec + 4u * sl, 0.0f);
             }
         }
         if (tid < 2 * F) { flags[tid] = 0; wcnt[tid] = 0; }
@@ -348,6 +363,12 @@ slot_minsum_kernel(const SlotTables tb, const DecodeArgs a)
                         float acc = lds_f32(smem, rec + 4) + lds_f32(smem, rec + 8);   // 0 + x + y == x + y
                         acc = acc + lds_f32(smem, rec + 12);
                         acc = acc + lds_f32(smem, rec + 16);
+                        if (DV > 4) {
+                            const int dg = (int)((cdeg >> (4 * k)) & 15u);
+#pragma unroll
+                            for (int sl = 4; sl < DV; ++sl)
+                                if (sl < dg) acc = acc + lds_f32(smem, rec + 4u + 4u * sl);
+                        }
                         lds_put_f32(smem, rec, acc + ycur[k]);                        // channel last, ldpc.py:322
                     }
                 }

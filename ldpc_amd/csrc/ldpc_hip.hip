@@ -972,6 +972,7 @@ struct ldpc_handle {
     // pipelined host entry point (large calls only): two slots and a stream for the uploads
     HostSlot slot[2];
     hipStream_t copy_stream = nullptr;
+    unsigned long long *pass_counts = nullptr;   // caller's device counters (ldpc_set_pass_counters), or null
     unsigned char *scratch = nullptr;   // this device's copy of the static scratch array
     Launch launch_cache[2][2][2];   // [algo][prec == 64][chained]; fn == nullptr: not chosen yet
 };
@@ -1336,6 +1337,13 @@ extern "C" int ldpc_set_minsum_scaling(ldpc_handle *h, float alpha, float beta)
     return 0;
 }
 
+extern "C" int ldpc_set_pass_counters(ldpc_handle *h, uint64_t *d_counts)
+{
+    if (!h) return fail(LDPC_E_ARG, "handle is NULL");
+    h->pass_counts = reinterpret_cast<unsigned long long *>(d_counts);
+    return 0;
+}
+
 extern "C" int ldpc_set_stream(ldpc_handle *h, void *hip_stream, int use_own)
 {
     if (!h) return fail(LDPC_E_ARG, "handle is NULL");
@@ -1456,41 +1464,58 @@ static size_t csr_ws_stride(const ldpc_handle *h, int prec)
 }
 
 // Short codes, float32: several frames per workgroup with explicit messages (edge_slots.h).
+// Message slots per column record: the instantiated class that covers the largest column degree.
+static int slots_dv(const ldpc_handle *h)
+{
+    return h->max_col_deg <= 4 ? 4 : h->max_col_deg <= 8 ? 8 : h->max_col_deg <= 12 ? 12 : 0;
+}
+
 static int slots_frames(const ldpc_handle *h)
 {
-    if (h->m <= 0 || h->m > 1024) return 0;
+    const int dv = slots_dv(h);
+    if (h->m <= 0 || h->m > 1024 || dv == 0) return 0;
     int F = std::min(1024 / h->m, 32);
-    while (F > 0 && SlotGeom(h->n, F).bytes > h->lds_max) --F;
+    while (F > 0 && SlotGeom(h->n, F, dv).bytes > h->lds_max) --F;
     return F;
+}
+
+template <bool SPA>
+static const void *slots_fn(int d, int dv)
+{
+    if (dv == 4)
+        return d <= 8    ? reinterpret_cast<const void *>(&slot_minsum_kernel<8, 4, SPA>)
+               : d <= 12 ? reinterpret_cast<const void *>(&slot_minsum_kernel<12, 4, SPA>)
+               : d <= 16 ? reinterpret_cast<const void *>(&slot_minsum_kernel<16, 4, SPA>)
+               : d <= 20 ? reinterpret_cast<const void *>(&slot_minsum_kernel<20, 4, SPA>)
+               : d <= 24 ? reinterpret_cast<const void *>(&slot_minsum_kernel<24, 4, SPA>) : nullptr;
+    if (dv == 8)
+        return d <= 12   ? reinterpret_cast<const void *>(&slot_minsum_kernel<12, 8, SPA>)
+               : d <= 16 ? reinterpret_cast<const void *>(&slot_minsum_kernel<16, 8, SPA>)
+               : d <= 24 ? reinterpret_cast<const void *>(&slot_minsum_kernel<24, 8, SPA>) : nullptr;
+    if (dv == 12)
+        return d <= 8    ? reinterpret_cast<const void *>(&slot_minsum_kernel<8, 12, SPA>)
+               : d <= 16 ? reinterpret_cast<const void *>(&slot_minsum_kernel<16, 12, SPA>) : nullptr;
+    return nullptr;
 }
 
 static bool slots_applies(const ldpc_handle *h, int prec, bool chained)
 {
     const char *off = hook("LDPC_HIP_NO_SLOTS");
     if (prec != 32 || chained || (off && off[0] == '1')) return false;
-    if (h->max_col_deg > 4 || h->max_row_deg > 24 || h->min_row_deg < 2) return false;
+    if (h->min_row_deg < 2 || !slots_fn<false>(h->max_row_deg, slots_dv(h))) return false;
     const int F = slots_frames(h);
     if (F < 1) return false;
     const int nt = (F * h->m + 63) / 64 * 64;
     return (long long)F * h->n <= (long long)SlotGeom::YMAX * nt;
 }
 
-template <bool SPA>
-static const void *slots_fn(int d)
-{
-    return d <= 8    ? reinterpret_cast<const void *>(&slot_minsum_kernel<8, SPA>)
-           : d <= 12 ? reinterpret_cast<const void *>(&slot_minsum_kernel<12, SPA>)
-           : d <= 16 ? reinterpret_cast<const void *>(&slot_minsum_kernel<16, SPA>)
-           : d <= 20 ? reinterpret_cast<const void *>(&slot_minsum_kernel<20, SPA>)
-                     : reinterpret_cast<const void *>(&slot_minsum_kernel<24, SPA>);
-}
-
 static int slots_pick(const ldpc_handle *h, bool spa, Launch *L)
 {
-    L->fn = spa ? slots_fn<true>(h->max_row_deg) : slots_fn<false>(h->max_row_deg);
+    const int dv = slots_dv(h);
+    L->fn = spa ? slots_fn<true>(h->max_row_deg, dv) : slots_fn<false>(h->max_row_deg, dv);
     L->fpw = slots_frames(h);
     L->block = (L->fpw * h->m + 63) / 64 * 64;
-    L->lds = SlotGeom(h->n, L->fpw).bytes;
+    L->lds = SlotGeom(h->n, L->fpw, dv).bytes;
     L->slots = true;
     return 0;
 }
@@ -1534,7 +1559,7 @@ static int select_kernel(ldpc_handle *h, int algo, int prec, bool chained, Launc
             // short codes, float32: several frames per workgroup (edge_slots.h)
             int rc = slots_pick(h, true, L);
             if (rc) return rc;
-            if ((rc = blocks_per_cu(h->device, L->fn, L->block, L->lds, &per_cu))) return rc;
+            if ((rc = blocks_per_cu(h->device, L->fn, L->block, L->lds, &per_cu, true))) return rc;
             L->max_grid = h->n_cu * per_cu;
             return 0;
         }
@@ -1565,7 +1590,7 @@ static int select_kernel(ldpc_handle *h, int algo, int prec, bool chained, Launc
     if (!(h->is_qc && planes_applies(h, prec, chained)) && slots_applies(h, prec, chained)) {
         int rc = slots_pick(h, false, L);
         if (rc) return rc;
-        if ((rc = blocks_per_cu(h->device, L->fn, L->block, L->lds, &per_cu))) return rc;
+        if ((rc = blocks_per_cu(h->device, L->fn, L->block, L->lds, &per_cu, true))) return rc;
         L->max_grid = h->n_cu * per_cu;
         return 0;
     }
@@ -1683,10 +1708,11 @@ static int launch_decode(ldpc_handle *h, int algo, int prec, const DecodeArgs &a
         }
     }
     DecodeArgs a = args;
+    a.pass_counts = h->pass_counts;
     if (L.slots) {
         SlotTables tb;
         tb.m = h->m; tb.n = h->n; tb.E = h->E; tb.F = L.fpw;
-        tb.row_ptr = h->csr.row_ptr; tb.col_idx = h->csr.col_idx; tb.edge_slot = h->edge_slot;
+        tb.row_ptr = h->csr.row_ptr; tb.col_idx = h->csr.col_idx; tb.edge_slot = h->edge_slot; tb.col_ptr = h->csr.col_ptr;
         if ((rc = claim_counter(h, L, &a, fixed))) return rc;
         void *kargs[] = {&tb, &a};
         HIP_TRY(hipLaunchKernel(L.fn, dim3(L.grid), dim3(L.block), kargs, L.lds, h->stream));

@@ -114,6 +114,11 @@ class Decoder:
         (1, 0) is the reference's plain min-sum."""
         _check(self._L.ldpc_set_minsum_scaling(self._h, float(alpha), float(beta)))
 
+    def set_pass_counters(self, d_counts):
+        """Device pointer to two uint64 (or None): the message-plane kernels add their numbers of full
+        and of syndrome-only check passes to them (measurement aid)."""
+        _check(self._L.ldpc_set_pass_counters(self._h, _ptr(d_counts)))
+
     def sync(self):
         _check(self._L.ldpc_sync(self._h))
 
