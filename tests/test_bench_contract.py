@@ -1,4 +1,4 @@
-"""The committed bench line (profiles/r01_f32_planes_bench.json, written by `python bench.py` on an
+"""The committed bench line (profiles/r02_f32_planes_bench.json, written by `python bench.py` on an
 MI355X) carries every field the measurement contract names, and the profile evidence beside it is
 consistent with it: the rocprofv3 kernel average agrees with the bench's own kernel time, and the
 HBM traffic from the counter passes is the algorithmic traffic to within a few percent."""
@@ -16,7 +16,7 @@ def _load(name):
 
 
 def test_bench_line_fields():
-    d = _load('r01_f32_planes_bench.json')
+    d = _load('r02_f32_planes_bench.json')
     for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
               'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
         assert k in d, k
@@ -40,20 +40,20 @@ def test_bench_line_fields():
 
 
 def test_rocprof_average_agrees_with_bench_kernel_time():
-    under = _load('r01_f32_planes_bench_under_rocprof.json')
-    with open(os.path.join(PROF, 'r01_f32_planes_kernel_stats.csv')) as f:
+    under = _load('r02_f32_planes_bench_under_rocprof.json')
+    with open(os.path.join(PROF, 'r02_f32_planes_kernel_stats.csv')) as f:
         rows = list(csv.DictReader(f))
     k = [r for r in rows if 'qc_planes_kernel' in r['Name']]
-    assert len(k) == 1 and int(k[0]['Calls']) == under['steps'] + under['warmup']
+    assert len(k) == 1 and int(k[0]['Calls']) == under['steps'] + under['warmup'] + 1      # + the launch that counts check passes
     avg_ms = float(k[0]['AverageNs']) * 1e-6
     assert abs(avg_ms - under['roofline']['kernel_ms']) / avg_ms < 0.01
     assert float(k[0]['Percentage']) > 90.0                      # the decode kernel is the run
 
 
 def test_counter_traffic_is_the_algorithmic_traffic():
-    s = _load('r01_f32_planes_pmc_summary.json')['derived']
+    s = _load('r02_f32_planes_pmc_summary.json')['derived']
     assert 0.99 < s['traffic_over_algorithmic'] < 1.05
-    d = _load('r01_f32_planes_bench.json')
+    d = _load('r02_f32_planes_bench.json')
     # (the bench reads the traffic from the counter summary committed at the time it runs)
     assert abs(d['roofline']['traffic'] - s['hbm_bytes_per_launch']) < 1e-3 * s['hbm_bytes_per_launch']
 
