@@ -64,7 +64,10 @@ int ldpc_device_count(void);
  * 161-181) and wifiMatrices.getWifiParityMatrix builds from its shift table
  * (wifiMatrices.py:12-34).
  * Replaces ldpcDecoder.__init__ (ldpc.py:225-247) and the dense device upload
- * of ldpcCUDA.py:538-564.  Limits: check degree <= 64, mb*roundup(Z,64) <= 1024.
+ * of ldpcCUDA.py:538-564.  Limits: check degree <= 64, mb*roundup(Z,64) <= 1024,
+ * nb <= 32*mb (LDPC_E_UNSUPPORTED beyond them: build the same matrix with
+ * ldpc_create_csr).  A code whose frame state does not fit the 160 KB of LDS in
+ * the arithmetic asked for is decoded from its edge list instead (slower, same results).
  */
 int ldpc_create_qc(int device, int Z, int mb, int nb, const int32_t *blk_ptr,
                    const int32_t *shifts, ldpc_handle **out);
@@ -99,7 +102,8 @@ int ldpc_set_pass_counters(ldpc_handle *h, uint64_t *d_counts);
 /* Make the handle launch on an existing HIP stream: hip_stream is a hipStream_t
  * passed as void* (NULL is the legacy default stream, which is a valid choice);
  * use_own != 0 ignores hip_stream and goes back to the stream the handle
- * created for itself.  No counterpart in the reference (numba's default
+ * created for itself.  A change of stream waits for what the handle has queued
+ * on the old one (its scratch buffers are shared between launches).  No counterpart in the reference (numba's default
  * stream, ldpcCUDA.py:594-662). */
 int ldpc_set_stream(ldpc_handle *h, void *hip_stream, int use_own);
 

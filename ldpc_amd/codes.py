@@ -254,18 +254,22 @@ def observation_to_qc(compressedMatrix):
 # first row of each (hexadecimal, most significant bit first; fileHandler.py:68-135, 144-160).
 def parse_generator_file(path, dim0, Z):
     """First rows of the circulants of B: uint8 [dim0 // Z][2][Z].  Line 2i holds the left,
-    line 2i+1 the right circulant of block-row i; a line of exactly Z+1 bits loses its
-    leading pad bit (fileHandler.py:126-135, 151-156)."""
+    line 2i+1 the right circulant of block-row i.  As in the reference (hexStringToBinaryArray and
+    hexToCirculant, fileHandler.py:68-135): only the characters 0-9 and A-F count (anything else on
+    the line is skipped), four bits each, most significant first, and the leading bit is dropped;
+    what remains must be exactly Z bits -- a malformed file fails here instead of producing a
+    generator of the wrong shape."""
     with open(path) as fid:
         lines = [ln.strip() for ln in fid.readlines()]
     rows = []
     for i in range(dim0 // Z):
         pair = []
         for ln in (lines[2 * i], lines[2 * i + 1]):
-            bits = np.unpackbits(np.frombuffer(bytes.fromhex(ln), dtype=np.uint8))
-            if len(bits) < Z:
-                raise ValueError('generator line shorter than the circulant size')
-            pair.append(bits[1:Z + 1].copy() if len(bits) > Z else bits)
+            digits = [int(ch, 16) for ch in ln if ch in '0123456789ABCDEF']
+            bits = np.array([(d >> k) & 1 for d in digits for k in (3, 2, 1, 0)], dtype=np.uint8)
+            if len(bits) != Z + 1:
+                raise ValueError(f'generator line holds {len(bits)} bits, expected {Z + 1} (a pad bit and {Z} of the circulant)')
+            pair.append(bits[1:].copy())
         rows.append(pair)
     return np.array(rows, dtype=np.uint8)
 

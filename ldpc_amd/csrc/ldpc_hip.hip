@@ -964,7 +964,12 @@ struct ldpc_handle {
     CsrTables csr{};
     const int32_t *edge_slot = nullptr;   // [E] rank of each edge's row inside its column
     int max_col_deg = 0, min_row_deg = 0;
-    std::vector<void *> tables;   // device allocations owned by the handle
+    // the code's tables: staged on the host while the handle is built, then ONE device allocation
+    // (taken from the per-device pool when a destroyed handle left one that is large enough)
+    std::vector<unsigned char> stage;
+    std::vector<std::pair<size_t, const void **>> fixups;    // (offset in stage, pointer to set)
+    void *arena = nullptr;
+    size_t arena_cap = 0;
     // staging for the host entry points
     DevBuf b_llr, b_hard, b_iters, b_conv, b_ones, b_soft, b_sig, b_sq, b_unc, b_cnt, b_pf, b_ws, b_work;
     // check-node state of the chained (stateful) decoder, one per arithmetic width
@@ -986,12 +991,39 @@ static size_t spa_state_bytes(const ldpc_handle *h, int prec)
 
 template <typename H> static int upload(ldpc_handle *h, const std::vector<H> &v, const H **out)
 {
-    void *d = nullptr;
-    const size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(H);
-    HIP_TRY(hipMalloc(&d, bytes));
-    h->tables.push_back(d);
-    if (!v.empty()) HIP_TRY(hipMemcpy(d, v.data(), v.size() * sizeof(H), hipMemcpyHostToDevice));
-    *out = reinterpret_cast<const H *>(d);
+    const size_t off = (h->stage.size() + 255) & ~(size_t)255;
+    h->stage.resize(off + std::max<size_t>(v.size(), 1) * sizeof(H));
+    if (!v.empty()) memcpy(h->stage.data() + off, v.data(), v.size() * sizeof(H));
+    h->fixups.emplace_back(off, reinterpret_cast<const void **>(out));
+    *out = nullptr;
+    return 0;
+}
+
+// What a destroyed handle leaves behind for the next one on the same device: its stream and its
+// table allocation.  The gym hands over a new matrix at every step (ldpc_env.py:313, 370), so
+// handles come and go at that rate; a stream creation and a dozen hipMalloc calls per step are
+// most of what a new handle costs.
+struct PooledParts { hipStream_t stream; void *arena; size_t cap; };
+static std::mutex g_pool_mutex;
+static std::vector<PooledParts> g_pool[64];
+enum { POOL_KEEP = 8 };
+
+// All staged tables to the device in one allocation and one copy; sets the table pointers.
+static int commit_tables(ldpc_handle *h)
+{
+    const size_t need = std::max<size_t>(h->stage.size(), 256);
+    if (h->arena_cap < need) {
+        if (h->arena) { (void)hipFree(h->arena); h->arena = nullptr; h->arena_cap = 0; }
+        const size_t cap = (need + 65535) & ~(size_t)65535;
+        HIP_TRY(hipMalloc(&h->arena, cap));
+        h->arena_cap = cap;
+    }
+    HIP_TRY(hipMemcpyAsync(h->arena, h->stage.data(), h->stage.size(), hipMemcpyHostToDevice, h->own_stream));
+    HIP_TRY(hipStreamSynchronize(h->own_stream));         // the staging vector goes away below
+    for (auto &f : h->fixups) *f.second = static_cast<const unsigned char *>(h->arena) + f.first;
+    h->stage.clear();
+    h->stage.shrink_to_fit();
+    h->fixups.clear();
     return 0;
 }
 
@@ -1035,7 +1067,17 @@ static int open_device(int device, ldpc_handle *h)
     h->device = device;
     h->n_cu = prop.multiProcessorCount;
     h->lds_max = prop.sharedMemPerBlock;
-    HIP_TRY(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+    {
+        std::lock_guard<std::mutex> g(g_pool_mutex);
+        if (device < 64 && !g_pool[device].empty()) {
+            const PooledParts p = g_pool[device].back();
+            g_pool[device].pop_back();
+            h->own_stream = p.stream;
+            h->arena = p.arena;
+            h->arena_cap = p.cap;
+        }
+    }
+    if (!h->own_stream) HIP_TRY(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
     h->stream = h->own_stream;
     return scratch_address(device, &h->scratch);     // with `device` current
 }
@@ -1054,7 +1096,17 @@ extern "C" void ldpc_destroy(ldpc_handle *h)
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->own_stream) { (void)hipStreamSynchronize(h->own_stream); }
-    for (void *p : h->tables) (void)hipFree(p);
+    if (h->stream != h->own_stream) (void)hipStreamSynchronize(h->stream);     // nothing may still read the tables
+    bool pooled = false;
+    if (h->own_stream && h->device < 64) {
+        std::lock_guard<std::mutex> g(g_pool_mutex);
+        if (g_pool[h->device].size() < POOL_KEEP) {
+            g_pool[h->device].push_back(PooledParts{h->own_stream, h->arena, h->arena_cap});
+            pooled = true;
+        }
+    }
+    if (pooled) { h->own_stream = nullptr; h->arena = nullptr; }
+    if (h->arena) (void)hipFree(h->arena);
     DevBuf *bufs[] = {&h->b_llr, &h->b_hard, &h->b_iters, &h->b_conv, &h->b_ones, &h->b_soft,
                       &h->b_sig, &h->b_sq, &h->b_unc, &h->b_cnt, &h->b_pf, &h->b_ws, &h->b_chain32, &h->b_chain64, &h->b_work};
     for (DevBuf *b : bufs) b->release();
@@ -1278,6 +1330,7 @@ extern "C" int ldpc_create_qc(int device, int Z, int mb, int nb, const int32_t *
             return rc;
         }
     }
+    if ((rc = commit_tables(h))) { ldpc_destroy(h); return rc; }
     *out = h;
     return 0;
 }
@@ -1310,7 +1363,7 @@ extern "C" int ldpc_create_csr(int device, int m, int n, const int32_t *row_ptr,
     if (rc) { delete h; return rc; }
     h->is_qc = false;
     h->m = m; h->n = n; h->E = E; h->max_row_deg = max_deg;
-    if ((rc = build_csr(h, rp, ci, m, n))) {
+    if ((rc = build_csr(h, rp, ci, m, n)) || (rc = commit_tables(h))) {
         ldpc_destroy(h);
         return rc;
     }
@@ -1347,7 +1400,14 @@ extern "C" int ldpc_set_pass_counters(ldpc_handle *h, uint64_t *d_counts)
 extern "C" int ldpc_set_stream(ldpc_handle *h, void *hip_stream, int use_own)
 {
     if (!h) return fail(LDPC_E_ARG, "handle is NULL");
-    h->stream = use_own ? h->own_stream : reinterpret_cast<hipStream_t>(hip_stream);
+    hipStream_t next = use_own ? h->own_stream : reinterpret_cast<hipStream_t>(hip_stream);
+    if (next != h->stream) {
+        // the frame-claim counter and the workspaces are per handle: what is queued on the old stream
+        // must have finished with them before a launch on the new one resets them
+        HIP_TRY(hipSetDevice(h->device));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    h->stream = next;
     return 0;
 }
 

@@ -27,10 +27,12 @@ def world():
 def init(backend=None):
     """Join the process group (no-op for a single process).  backend None: "nccl" when every
     local rank has a GPU of its own, else "gloo"."""
+    rank, local_rank, ws = world()
+    if ws == 1:
+        return
     import torch
     import torch.distributed as dist
-    rank, local_rank, ws = world()
-    if ws == 1 or dist.is_initialized():
+    if dist.is_initialized():
         return
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     if backend is None:
@@ -47,6 +49,16 @@ def local_device():
     """Card of this rank: LOCAL_RANK, wrapped when there are more local ranks than cards
     (ranks then share a card; meant for rehearsals on a one-GPU box)."""
     return world()[1] % max(device_count(), 1)
+
+
+def _require_group():
+    """The launcher started several ranks (WORLD_SIZE > 1): their shards are only a result once they
+    have been summed, so a forgotten init() is an error, not a silent per-rank answer."""
+    if world()[2] > 1:
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            raise RuntimeError('WORLD_SIZE > 1 but torch.distributed is not initialised: call '
+                               'ldpc_amd.distributed.init() (or init_process_group) before sweep / evaluate_variants')
 
 
 def frame_range(total, rank, world_size):
@@ -102,6 +114,7 @@ def sweep(code, snr_db, frames_per_snr, seed, max_iters=50, prec=32, algo=ALGO_M
     [n_snr, frames_per_snr, 4] in global frame order or None) on EVERY rank.
     `evaluate(snr, count, seed, first_frame, per_frame)` may replace the local engine call
     (it must return what Decoder.eval_awgn returns)."""
+    _require_group()
     rank, local_rank, ws = world()
     first, count = frame_range(frames_per_snr, rank, ws)
     snr = np.atleast_1d(np.asarray(snr_db, dtype=np.float64))
@@ -137,6 +150,7 @@ def evaluate_variants(variants, snr_db, frames_per_snr, seed, max_iters=50, prec
     Every variant sees the same noise (same seed, frames 0..frames_per_snr-1), as the
     reference's environment re-seeds per evaluation (ldpc_env.py:367-371).
     Returns counters uint64 [n_variants, n_snr, 6] on every rank."""
+    _require_group()
     rank, local_rank, ws = world()
     snr = np.atleast_1d(np.asarray(snr_db, dtype=np.float64))
     out = np.zeros((len(variants), len(snr), 6), np.uint64)

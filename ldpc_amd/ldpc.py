@@ -64,33 +64,71 @@ def modulate(vector, length):
 
 
 # ------------------------------------------------------------------ decoder cache
-_DECODERS = {}
+_DECODERS = {}              # key -> [engine, users]; insertion order = least recently used first
 _DECODERS_MAX = 16
 _DECODERS_LOCK = threading.Lock()
 
 
-def _engine_for(H, device=None, physical_device=None):
-    """HIP decoder for H (dense array or codes.QCCode).  The gym hands over a new
-    dense matrix at every step (ldpc_env.py:313, 370), so engines are cached by
-    content and the least recently used one is dropped.  `device` is the caller's
-    (logical) device number and part of the cache key -- a handle serves one host
-    thread at a time, so two logical devices never share one even when they map
-    to the same physical device (`physical_device`, default = `device`)."""
-    device = LDPC_HIP_DEVICE if device is None else device
-    physical_device = device if physical_device is None else physical_device
+def _code_key(H):
+    """(what to build the engine from, cache key).  A dense matrix is first read as block-circulant
+    (codes.detect_qc verifies every entry): its shift lists are the key, a few hundred integers
+    instead of a hash over the 8.4 M entries the gym hands over at every step (ldpc_env.py:313, 370).
+    Only a matrix without that structure is hashed."""
     if isinstance(H, codes.QCCode):
-        key = (device,) + H.key()
-    else:
-        Ha = np.ascontiguousarray(np.asarray(H) != 0)
-        key = (device, Ha.shape, hashlib.sha1(np.packbits(Ha).tobytes()).hexdigest())
-    with _DECODERS_LOCK:
-        eng = _DECODERS.pop(key, None)
-        if eng is None:
-            eng = Decoder(H, device=physical_device)
-            while len(_DECODERS) >= _DECODERS_MAX:
-                _DECODERS.pop(next(iter(_DECODERS))).close()
-        _DECODERS[key] = eng
-    return eng
+        return H, H.key()
+    Ha = np.asarray(H)
+    qc = codes.detect_qc(Ha)
+    if qc is not None:
+        return qc, qc.key()
+    bits = np.ascontiguousarray(Ha != 0)
+    return Ha, ('dense', bits.shape, hashlib.sha1(np.packbits(bits).tobytes()).hexdigest())
+
+
+def _evict_idle():
+    """Close least recently used engines nobody holds while the cache is over its size (lock held)."""
+    if len(_DECODERS) > _DECODERS_MAX:
+        for k in [k for k, e in _DECODERS.items() if e[1] == 0][:len(_DECODERS) - _DECODERS_MAX]:
+            _DECODERS.pop(k)[0].close()
+
+
+class _Lease:
+    """An engine of the cache, held for the duration of a `with` block.  An engine in use is never
+    closed: eviction skips it (the cache may exceed its size for a while), and an engine that was
+    dropped from the cache while in use is closed by its last user."""
+
+    def __init__(self, H, device=None, physical_device=None):
+        device = LDPC_HIP_DEVICE if device is None else device
+        physical_device = device if physical_device is None else physical_device
+        code, key = _code_key(H)
+        key = (device,) + tuple(key)
+        with _DECODERS_LOCK:
+            entry = _DECODERS.pop(key, None)
+            if entry is None:
+                entry = [Decoder(code, device=physical_device), 0]
+            _DECODERS[key] = entry                       # most recently used last
+            entry[1] += 1
+            _evict_idle()
+        self._key, self._entry = key, entry
+        self.engine = entry[0]
+
+    def __enter__(self):
+        return self.engine
+
+    def __exit__(self, *exc):
+        with _DECODERS_LOCK:
+            self._entry[1] -= 1
+            if self._entry[1] == 0 and _DECODERS.get(self._key) is not self._entry:
+                self._entry[0].close()                   # dropped from the cache meanwhile: the last user closes it
+            _evict_idle()
+        return False
+
+
+def _engine_lease(H, device=None, physical_device=None):
+    """`with _engine_lease(H, d) as eng:` -- HIP decoder for H (dense array or codes.QCCode) from a
+    cache keyed by content.  `device` is the caller's (logical) device number and part of the key:
+    a handle serves one host thread at a time, so two logical devices never share one even when they
+    map to the same physical device (`physical_device`, default = `device`)."""
+    return _Lease(H, device, physical_device)
 
 
 class ldpcDecoder:

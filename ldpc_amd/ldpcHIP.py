@@ -59,7 +59,11 @@ def evaluateCodeCuda(seed, SNRpoints, numberOfIterations, parityMatrix, numOfTra
     assert (seed > 0)
     assert hasattr(SNRpoints, "__len__")
     n_dev = max(device_count(), 1)
-    eng = _ldpc._engine_for(parityMatrix, cudaDeviceNumber, cudaDeviceNumber % n_dev)
+    with _ldpc._engine_lease(parityMatrix, cudaDeviceNumber, cudaDeviceNumber % n_dev) as eng:
+        return _evaluate_on(eng, seed, SNRpoints, numberOfIterations, numOfTransmissions, prec, deviceRng)
+
+
+def _evaluate_on(eng, seed, SNRpoints, numberOfIterations, numOfTransmissions, prec, deviceRng):
     n = eng.n
     berStats = common.berStatistics()
     if deviceRng:
@@ -89,6 +93,7 @@ def evaluateCodeCudaWrapper(seeds, SNRpoints, numberOfIterations, parityMatrix, 
     devices beyond the visible ones wrap around (device d -> d mod visible)."""
     berStats = common.berStatistics()
     newNumOfTransmissions = numOfTransmissions // numberOfCudaDevices
+    parityMatrix, _ = _ldpc._code_key(parityMatrix)       # the structure of a dense matrix is read once, not per device
     with concurrent.futures.ThreadPoolExecutor(max_workers=max(1, numberOfCudaDevices)) as pool:
         futs = [pool.submit(evaluateCodeCuda, seeds[d], SNRpoints, numberOfIterations, parityMatrix,
                             newNumOfTransmissions, 'None', d, prec, deviceRng)

@@ -144,3 +144,71 @@ def test_recursive_linear_fit():
     snr, ber, p, trend, itr = common.recursiveLinearFit(x, y)
     assert itr == 10 and len(snr) == len(ber) and np.all(trend(snr) > 0)
     assert np.allclose(p, np.polyfit(snr, ber, 1))
+
+
+def test_engine_cache_never_closes_an_engine_in_use(monkeypatch):
+    """The cache of ldpc_amd.ldpc (one engine per (device, code)) evicts least recently used engines,
+    but never one that a caller still holds; an engine dropped while in use is closed by its last user."""
+    from ldpc_amd import codes, ldpc
+
+    class Fake:
+        live = set()
+
+        def __init__(self, code, device=0):
+            self.code, self.closed = code, False
+            Fake.live.add(self)
+
+        def close(self):
+            assert not self.closed
+            self.closed = True
+            Fake.live.discard(self)
+
+    monkeypatch.setattr(ldpc, 'Decoder', Fake)
+    monkeypatch.setattr(ldpc, '_DECODERS', {})
+    monkeypatch.setattr(ldpc, '_DECODERS_MAX', 3)
+    base = codes.near_earth()
+    variants = [base.with_block(0, j, [1, 2 + j]) for j in range(6)]
+    held = [ldpc._engine_lease(v, 0) for v in variants[:4]]           # four engines in use, cache size 3
+    engines = [h.__enter__() for h in held]
+    assert len(Fake.live) == 4 and not any(e.closed for e in engines)
+    with ldpc._engine_lease(variants[4], 0) as e5:                    # a fifth: nothing idle to evict
+        assert len(Fake.live) == 5 and not e5.closed
+    assert e5.closed and len(ldpc._DECODERS) == 4                     # idle and over the limit at the next insertion: evicted
+    held[0].__exit__(None, None, None)
+    with ldpc._engine_lease(variants[5], 0):
+        pass
+    assert engines[0].closed and not engines[1].closed                # the idle one went, the busy ones stayed
+    with ldpc._engine_lease(variants[1], 0) as again:
+        assert again is engines[1]                                    # same key, same engine
+    for h in held[1:]:
+        h.__exit__(None, None, None)
+    assert not any(e.closed for e in engines[1:] if e in [v[0] for v in ldpc._DECODERS.values()])
+    # a dense matrix and its shift lists share one engine
+    with ldpc._engine_lease(variants[2].to_dense(), 0) as dense_eng:
+        assert dense_eng is engines[2] or dense_eng.code.key() == variants[2].key()
+
+
+def test_sweep_refuses_an_uninitialised_process_group(monkeypatch):
+    from ldpc_amd import codes, distributed
+    monkeypatch.setenv('WORLD_SIZE', '2')
+    monkeypatch.setenv('RANK', '0')
+    with pytest.raises(RuntimeError, match='not initialised'):
+        distributed.sweep(codes.near_earth(), [3.0], 10, seed=1, evaluate=lambda *a: None)
+    with pytest.raises(RuntimeError, match='not initialised'):
+        distributed.evaluate_variants([codes.near_earth()], [3.0], 10, seed=1, evaluate=lambda *a: None)
+
+
+def test_generator_file_parsing_follows_the_reference(tmp_path):
+    from ldpc_amd import codes
+    Z = 7
+    good = tmp_path / 'g.txt'
+    good.write_text('a5\nFF\n')                       # lower-case digits do not count: 'a5' holds one digit
+    with pytest.raises(ValueError, match='bits'):
+        codes.parse_generator_file(str(good), Z, Z)
+    good.write_text('A5 \n 0F\n')                    # 8 bits each: pad bit + 7
+    rows = codes.parse_generator_file(str(good), Z, Z)
+    assert rows.shape == (1, 2, 7)
+    assert rows[0, 0].tolist() == [0, 1, 0, 0, 1, 0, 1] and rows[0, 1].tolist() == [0, 0, 0, 1, 1, 1, 1]
+    good.write_text('A5A\n0F\n')
+    with pytest.raises(ValueError):
+        codes.parse_generator_file(str(good), Z, Z)
