@@ -149,3 +149,29 @@ def compress(H):
         padded[mask] = H[r, :] != 0
         out.append(np.packbits(padded))
     return np.hstack(out)
+
+
+# ---------------------------------------------------------------------------
+# Monte-Carlo confidence intervals of an evaluation (not in the reference, which reports point
+# estimates only, common.py:195-227).
+def wilson_interval(errors, trials, z=1.96):
+    """Wilson score interval (default 95 %) of a proportion errors / trials, as (low, high)."""
+    if trials <= 0:
+        return 0.0, 1.0
+    p = errors / trials
+    d = 1.0 + z * z / trials
+    mid = (p + z * z / (2 * trials)) / d
+    half = z * np.sqrt((p * (1 - p) + z * z / (4 * trials)) / trials) / d
+    return max(mid - half, 0.0), min(mid + half, 1.0)
+
+
+def ber_interval(bit_errors_per_frame, n, z=1.96):
+    """(ber, low, high): bit error rate with a normal-approximation interval whose sampling unit is
+    the FRAME -- bit errors come in bursts inside the frames that fail, so treating the n bits of a
+    frame as independent trials would understate the spread by orders of magnitude."""
+    e = np.asarray(bit_errors_per_frame, dtype=np.float64)
+    if e.size == 0:
+        return 0.0, 0.0, 1.0
+    ber = e.mean() / n
+    half = z * e.std(ddof=1) / np.sqrt(e.size) / n if e.size > 1 else 1.0
+    return ber, max(ber - half, 0.0), ber + half

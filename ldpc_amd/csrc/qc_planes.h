@@ -192,6 +192,7 @@ planes_check_pass(unsigned char *smem, const uint32_t (&radr)[CPT * 4], int D, i
     uint32_t idx = 0, R = 0;
     unsigned long long synd = synd0;     // set for every row if rows have an odd number of missing edges (each reads as hard decision 1)
     uint32_t RX = 0;                     // bit x: v < 0 on extra edge x
+    uint32_t LT = 0;                     // one bit per slot edge: it lowered the running minimum
     if (HEAVY) {
         // The extra edges first (minimum, second minimum and sign product do not depend on the order
         // edges are visited in; equal magnitudes make min2 == min1, so neither does the result of argmin).
@@ -248,15 +249,20 @@ planes_check_pass(unsigned char *smem, const uint32_t (&radr)[CPT * 4], int D, i
                 synd ^= __ballot(p[cb][u] > 0.0f);                          // slicer, ldpc.py:47
                 const float v = FIRST ? p[cb][u] : p[cb][u] - c[cb][u];     // receive, ldpc.py:161 (x - 0 == x)
                 R = __builtin_amdgcn_alignbit(R, __float_as_uint(v), 31);   // (R << 1) | sign(v), ldpc.py:139
-                const float av = fabsf(v);                                  // ldpc.py:178
-                const bool lt = av < min1;
-                idx = lt ? (uint32_t)s : idx;
                 // second minimum and minimum as bare instructions: behind the register pins below the
                 // compiler no longer knows that min1/min2 are canonical and would put a v_max x, x
-                // in front of its own med3 / min once per chunk
+                // in front of its own med3 / min once per chunk  (|v|: ldpc.py:178)
                 float n2, n1;
                 asm("v_med3_f32 %0, %1, %2, |%3|" : "=v"(n2) : "v"(min1), "v"(min2), "v"(v));
                 asm("v_min_f32 %0, %1, |%2|" : "=v"(n1) : "v"(min1), "v"(v));
+                // arg-min: one bit per edge, "this edge lowered the minimum", shifted into LT through the
+                // carry -- the integer difference of the new and the old minimum borrows exactly when
+                // |v| < min1 (non-negative floats order like their bit patterns).  Two full-rate
+                // instructions where a compare and a select are two half-rate ones; the edge itself is
+                // read off the lowest set bit after the loop.
+                uint32_t borrow_tmp;
+                asm("v_sub_co_u32 %1, vcc, %2, %3\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
+                    : "+v"(LT), "=&v"(borrow_tmp) : "v"(n1), "v"(min1) : "vcc");
                 min2 = n2;
                 min1 = n1;
             }
@@ -265,11 +271,14 @@ planes_check_pass(unsigned char *smem, const uint32_t (&radr)[CPT * 4], int D, i
             // |v|, every intermediate minimum and every compare mask alive until then
             // (60+ vector and 60+ scalar registers, spills).
             if ((u & 3) == 3) {
-                asm volatile("" : "+v"(min1), "+v"(min2), "+v"(idx), "+v"(R), "+s"(synd));
+                asm volatile("" : "+v"(min1), "+v"(min2), "+v"(LT), "+v"(R), "+s"(synd));
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
+    // the last slot edge that lowered the minimum is the arg-min (bit NS-1-s of LT belongs to edge s),
+    // unless no slot edge went below what the extra edges left
+    if (LT != 0u) idx = (uint32_t)(NS - 1) - (uint32_t)__builtin_ctz(LT);
     // R: D sign bits, first edge highest.  Left-align and fold in the product of all signs:
     // a bit of T is then the sign of the outgoing message itself (ldpc.py:190)
     if (NS < 32) R <<= (32 - NS);

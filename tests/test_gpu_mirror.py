@@ -156,3 +156,37 @@ def test_near_earth_quality_anchor_of_the_reference_notebook():
     assert abs(p[0] - (-0.05026939)) < 0.005 and abs(p[1] - 0.17176406) < 0.015
     integ = (np.poly1d([1]) - np.poly1d(p)).integ()
     assert abs((integ(roi[-1]) - integ(roi[0])) - 0.39563919692811345) < 3e-4
+
+
+@pytest.mark.gpu
+def test_device_noise_curve_within_monte_carlo_interval_of_the_oracle(oracle_mod):
+    """FER / BER of the sweep driver (noise generated on the device, float32 kernels) against the CPU
+    oracle decoding an INDEPENDENT sample drawn on the host the way the reference draws it
+    (ldpcCUDA.py:509-517): the two estimates of every point must agree within their joint Monte-Carlo
+    spread (3 sigma of the difference, frame as the sampling unit), and the oracle's estimate must
+    lie inside the 99.7 % interval the confidence-interval helpers give for the device's."""
+    import ldpc_amd
+    from ldpc_amd import codes, common
+    from conftest import make_llrs
+    qc = codes.near_earth()
+    orc = oracle_mod.Oracle(qc.to_dense())
+    snrs, Fg, Fc = [3.0, 3.2, 3.4], 20000, 1500
+    with ldpc_amd.Decoder(qc) as eng:
+        cnt, pf = eng.eval_awgn(snrs, Fg, seed=20261111, per_frame=True)
+    for k, snr in enumerate(snrs):
+        hard, iters, conv, _ = orc.minsum(make_llrs(77 + k, snr, qc.n, Fc), 50, prec=32, want_soft=False, threads=16)
+        e_c = hard.sum(1).astype(np.float64)
+        e_g = pf[k, :, 2].astype(np.float64)
+        fer_g, fer_c = (e_g > 0).mean(), (e_c > 0).mean()
+        sd = np.sqrt(fer_g * (1 - fer_g) / Fg + fer_c * (1 - fer_c) / Fc)
+        assert abs(fer_g - fer_c) <= 3 * sd + 1e-12, (snr, fer_g, fer_c, sd)
+        ber_g, ber_c = e_g.mean() / qc.n, e_c.mean() / qc.n
+        sdb = np.sqrt(e_g.var(ddof=1) / Fg + e_c.var(ddof=1) / Fc) / qc.n
+        assert abs(ber_g - ber_c) <= 3 * sdb + 1e-12, (snr, ber_g, ber_c, sdb)
+        it_g, it_c = pf[k, :, 3].astype(np.float64), iters.astype(np.float64)
+        assert abs(it_g.mean() - it_c.mean()) <= 3 * np.sqrt(it_g.var(ddof=1) / Fg + it_c.var(ddof=1) / Fc)
+        lo, hi = common.wilson_interval(int((e_g > 0).sum()), Fg, z=3.0)
+        assert lo - 3 * np.sqrt(fer_c * (1 - fer_c) / Fc) <= fer_c <= hi + 3 * np.sqrt(fer_c * (1 - fer_c) / Fc)
+        b, blo, bhi = common.ber_interval(e_g, qc.n)
+        assert blo <= b <= bhi and b == ber_g
+    assert (pf[0, :, 2] > 0).mean() > 0.5 > (pf[2, :, 2] > 0).mean()       # the points straddle the waterfall

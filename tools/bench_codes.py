@@ -9,6 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def main():
+    os.environ['LDPC_HIP_TEST_HOOKS'] = '1'         # one case forces the older kernel family for comparison
     import torch
     import ldpc_amd
     from ldpc_amd import codes
@@ -17,6 +18,7 @@ def main():
     cases = [
         # name, code, info bits, frames, snr dB, prec, algo, sign mode
         ('nearEarth min-sum f32', codes.near_earth(), 7154, 400000, 3.5, 32, 0, 0),
+        ('nearEarth min-sum f32 on the compressed-row-state kernel (message planes switched off)', codes.near_earth(), 7154, 200000, 3.5, 32, 0, 0),
         ('nearEarth min-sum f64', codes.near_earth(), 7154, 200000, 3.5, 64, 0, 0),
         ('nearEarth sum-product f32', codes.near_earth(), 7154, 200000, 3.5, 32, 1, 0),
         ('nearEarth block (1,3) zeroed min-sum f32', codes.near_earth_zeroed(1, 3), 7154, 200000, 3.5, 32, 0, 0),
@@ -27,6 +29,10 @@ def main():
     ]
     out = []
     for name, code, k, F, snr, prec, algo, sm in cases:
+        if 'switched off' in name:
+            os.environ['LDPC_HIP_NO_PLANES'] = '1'
+        else:
+            os.environ.pop('LDPC_HIP_NO_PLANES', None)
         with ldpc_amd.Decoder(code) as eng:
             eng.set_stream(stream.cuda_stream)
             n = eng.n

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """The reference's evaluation grid on one GPU: NearEarth, plain min-sum, <= 50 iterations,
 SNR 2.5:0.25:4.5 dB, `--frames` frames per point through the sweep driver (channel on the device,
-decode, counters).  Prints one JSON object: per point BER, FER, mean iterations, wall time."""
+decode, counters).  Prints one JSON object: per point BER and FER with their 95 % confidence intervals
+(frame as the sampling unit), mean iterations, wall time."""
 import argparse
 import json
 import os
@@ -19,7 +20,7 @@ def main():
     args = ap.parse_args()
     import numpy as np
     import ldpc_amd
-    from ldpc_amd import codes
+    from ldpc_amd import codes, common
     snr = [round(2.5 + 0.25 * k, 2) for k in range(9)]
     rows = []
     with ldpc_amd.Decoder(codes.near_earth()) as eng:
@@ -27,10 +28,12 @@ def main():
         t_all = time.perf_counter()
         for s in snr:
             t0 = time.perf_counter()
-            cnt, _ = eng.eval_awgn([s], args.frames, seed=args.seed, prec=args.prec)
+            cnt, pf = eng.eval_awgn([s], args.frames, seed=args.seed, prec=args.prec, per_frame=True)
             dt = time.perf_counter() - t0
             frames, ferr, berr, itsum, unc, notcw = [int(x) for x in cnt[0]]
-            rows.append(dict(snr_db=s, frames=frames, fer=ferr / frames, ber=berr / (frames * eng.n),
+            _, b_lo, b_hi = common.ber_interval(pf[0, :, 2], eng.n)
+            rows.append(dict(snr_db=s, frames=frames, fer=ferr / frames, fer_ci95=list(common.wilson_interval(ferr, frames)),
+                             ber=berr / (frames * eng.n), ber_ci95=[b_lo, b_hi],
                              uncoded_ber=unc / (frames * eng.n), mean_iters=itsum / frames,
                              not_codeword=notcw, wall_s=dt, info_gbps=7154 * frames / dt / 1e9))
             print(f'{s:5.2f} dB  FER {rows[-1]["fer"]:.3e}  BER {rows[-1]["ber"]:.3e}  iters {rows[-1]["mean_iters"]:6.2f}  '
