@@ -244,7 +244,6 @@ planes_check_pass(unsigned char *smem, const uint32_t (&radr)[CPT * 4], int D, i
         const int cb = k & 1;
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
-            const int s = k * CH + u;
             {
                 synd ^= __ballot(p[cb][u] > 0.0f);                          // slicer, ldpc.py:47
                 const float v = FIRST ? p[cb][u] : p[cb][u] - c[cb][u];     // receive, ldpc.py:161 (x - 0 == x)
