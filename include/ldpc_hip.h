@@ -174,7 +174,10 @@ int ldpc_decode_device(ldpc_handle *h, int algo, int prec, int sign_mode, int ma
  * so the call reaches no hipMalloc / hipFree.  A code whose kernel needs a workspace gets as
  * many workgroups as fit the array (results do not depend on that; it only runs slower).
  * Fails with LDPC_E_UNSUPPORTED if not even one workspace fits, or if n_frames is beyond
- * 2^31 - 1 - 4 * (workgroups launched).  All calls on one GPU share the array: two of them
+ * 2^31 - 1 - 4 * (workgroups launched), or if the decode needs the handle's edge list and that
+ * is not on the device yet (ldpc_create_qc defers it for codes of 2 x 16 circulants of size 511,
+ * which need it only for float64 sum-product and the table-driven kernel: run such a decode once
+ * through ldpc_decode_device first).  All calls on one GPU share the array: two of them
  * that overlap in time (different handles or streams on the same GPU) race; calls on one
  * stream, or separated by a synchronisation, are safe.
  */
@@ -210,6 +213,8 @@ int ldpc_channel_awgn_device(ldpc_handle *h, double snr_db, uint64_t seed, uint6
  *   per_frame [n_snr][frames_per_snr][4] float or NULL: sigma_hat, uncoded
  *             errors, decoded errors, iterations  (the columns of a
  *             berStatistics row, common.py:149-157)
+ * A sweep of at most 8 points and 8192 frames in all runs as one launch, the
+ * points' frames side by side (same noise and results as point after point).
  * Synchronous.  Replaces the SNR x transmissions loops of ldpc.evaluateCode
  * (ldpc.py:350-388) and ldpcCUDA.evaluateCodeCuda (ldpcCUDA.py:576-664).
  */

@@ -97,9 +97,14 @@ def recursiveLinearFit(xData, yData, numberOfIterations=10, earlyStopping=False)
         p = np.polyfit(snr, ber, 1)
         trendP = np.poly1d(p)
         keep = trendP(snr) > 0
-        ber = ber[keep]
-        snr = snr[trendP(snr) > 0]
         itr += 1
+        if keep.all():
+            # nothing dropped: every remaining round would fit the same points again and get the same
+            # line (the gym calls this once per step; ten fits were most of a step's host time)
+            itr = max(itr, numberOfIterations)
+            break
+        ber = ber[keep]
+        snr = snr[keep]
     return snr, ber, p, trendP, itr
 
 

@@ -90,6 +90,8 @@ struct CsrTables {
     const int32_t *col_e;    // [E] edge number of that entry inside its row
 };
 
+enum { GEN_MAX_POINTS = 8, GEN_MAX_BATCH = 8192 };   // sweep points, and frames in all, that one launch may serve
+
 struct DecodeArgs {
     const void *llr;       // [frames][n] float32, or float64 if llr_f64
     int llr_f64;
@@ -116,6 +118,12 @@ struct DecodeArgs {
     unsigned long long gen_seed = 0, gen_first_frame = 0;
     uint32_t gen_stream = 0;
     float gen_sigma = 0.0f;
+    // Several noise streams in one launch (a small sweep: the points' frames decode side by side instead of
+    // one launch after the other).  gen_per_point > 0: frame f of the launch belongs to point p = f / gen_per_point
+    // and is frame gen_first_frame + f % gen_per_point of stream gen_stream + p, made with gen_point_sigma[p]
+    // and scaled by gen_point_scale[p] (gen_sigma and llr_scale are then unused).
+    uint32_t gen_per_point = 0;
+    float gen_point_sigma[GEN_MAX_POINTS] = {}, gen_point_scale[GEN_MAX_POINTS] = {};
     int32_t *gen_uncoded = nullptr;              // [frames] channel hard-decision errors, or null
     unsigned long long *gen_sumsq = nullptr;     // [frames] sum of z^2 in 2^-19 fixed point (awgn.h), or null
     // null, or [2] summed over the launch: full check passes, syndrome-only passes (measurement only)
@@ -773,12 +781,35 @@ channel_awgn_kernel(uint64_t seed, uint32_t stream, uint64_t first_frame, int64_
     }
 }
 
+struct PointSigmas { float sigma[GEN_MAX_POINTS]; };
+
 // counters[6]: frames, frame errors, decoded bit errors, iterations, uncoded bit errors, not-a-codeword
 __global__ void __launch_bounds__(256)
 accumulate_kernel(int64_t n_frames, int n, float sigma, const int32_t *iters, const uint8_t *conv, const int32_t *ones,
                   const int32_t *uncoded, const float *sigma_hat, const unsigned long long *sumsq,
-                  unsigned long long *counters, float *per_frame)
+                  unsigned long long *counters, float *per_frame, uint32_t per_point, PointSigmas points)
 {
+    if (per_point) {
+        // a launch that served several sweep points (at most GEN_MAX_BATCH frames): frame f counts for point f / per_point
+        for (int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; f < n_frames;
+             f += (int64_t)gridDim.x * blockDim.x) {
+            const uint32_t pt = (uint32_t)f / per_point;
+            unsigned long long *c = counters + 6 * pt;
+            atomicAdd(&c[0], 1ull);
+            if (ones[f]) { atomicAdd(&c[1], 1ull); atomicAdd(&c[2], (unsigned long long)ones[f]); }
+            if (iters[f]) atomicAdd(&c[3], (unsigned long long)iters[f]);
+            if (uncoded[f]) atomicAdd(&c[4], (unsigned long long)uncoded[f]);
+            if (conv[f] == 0) atomicAdd(&c[5], 1ull);
+            if (per_frame) {
+                float *p = per_frame + 4 * f;
+                p[0] = awgn_sigma_hat(sumsq[f], points.sigma[pt], n);
+                p[1] = (float)uncoded[f];
+                p[2] = (float)ones[f];
+                p[3] = (float)iters[f];
+            }
+        }
+        return;
+    }
     unsigned long long c[6] = {0, 0, 0, 0, 0, 0};
     for (int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; f < n_frames;
          f += (int64_t)gridDim.x * blockDim.x) {
@@ -970,6 +1001,13 @@ struct ldpc_handle {
     std::vector<std::pair<size_t, const void **>> fixups;    // (offset in stage, pointer to set)
     void *arena = nullptr;
     size_t arena_cap = 0;
+    // The edge list of a block-circulant code is built when a kernel that walks it is first chosen: a code
+    // the message-plane kernels decode never needs it, and the gym makes a new handle per step
+    // (ldpc_env.py:313, 370), where sorting 32,704 edges and copying 0.8 MB of tables was most of the cost.
+    bool edges_ready = false;
+    std::vector<int32_t> qc_blk_ptr, qc_shifts;    // the code as ldpc_create_qc received it, until then
+    void *edge_arena = nullptr;
+    size_t edge_arena_cap = 0;
     // staging for the host entry points
     DevBuf b_llr, b_hard, b_iters, b_conv, b_ones, b_soft, b_sig, b_sq, b_unc, b_cnt, b_pf, b_ws, b_work;
     // check-node state of the chained (stateful) decoder, one per arithmetic width
@@ -1003,24 +1041,34 @@ template <typename H> static int upload(ldpc_handle *h, const std::vector<H> &v,
 // table allocation.  The gym hands over a new matrix at every step (ldpc_env.py:313, 370), so
 // handles come and go at that rate; a stream creation and a dozen hipMalloc calls per step are
 // most of what a new handle costs.
-struct PooledParts { hipStream_t stream; void *arena; size_t cap; };
+// Its small staging and result buffers travel along (a sweep of 3 x 10 frames on a fresh handle spent
+// more time in eight hipMalloc calls than in its kernels); large ones are freed as before.
+enum { POOL_KEEP = 8, POOL_BUFS = 13, POOL_BUF_MAX = 4 << 20 };
+struct PooledParts { hipStream_t stream; void *arena; size_t cap; DevBuf bufs[POOL_BUFS]; };
 static std::mutex g_pool_mutex;
 static std::vector<PooledParts> g_pool[64];
-enum { POOL_KEEP = 8 };
+
+// The buffers of a handle that hold nothing between calls, in the order they are pooled in.
+static void scratch_buffers(ldpc_handle *h, DevBuf *(&out)[POOL_BUFS])
+{
+    DevBuf *all[POOL_BUFS] = {&h->b_llr, &h->b_hard, &h->b_iters, &h->b_conv, &h->b_ones, &h->b_soft, &h->b_sig,
+                              &h->b_sq, &h->b_unc, &h->b_cnt, &h->b_pf, &h->b_ws, &h->b_work};
+    for (int k = 0; k < POOL_BUFS; ++k) out[k] = all[k];
+}
 
 // All staged tables to the device in one allocation and one copy; sets the table pointers.
-static int commit_tables(ldpc_handle *h)
+static int commit_tables(ldpc_handle *h, void **arena, size_t *arena_cap)
 {
     const size_t need = std::max<size_t>(h->stage.size(), 256);
-    if (h->arena_cap < need) {
-        if (h->arena) { (void)hipFree(h->arena); h->arena = nullptr; h->arena_cap = 0; }
+    if (*arena_cap < need) {
+        if (*arena) { (void)hipFree(*arena); *arena = nullptr; *arena_cap = 0; }
         const size_t cap = (need + 65535) & ~(size_t)65535;
-        HIP_TRY(hipMalloc(&h->arena, cap));
-        h->arena_cap = cap;
+        HIP_TRY(hipMalloc(arena, cap));
+        *arena_cap = cap;
     }
-    HIP_TRY(hipMemcpyAsync(h->arena, h->stage.data(), h->stage.size(), hipMemcpyHostToDevice, h->own_stream));
+    HIP_TRY(hipMemcpyAsync(*arena, h->stage.data(), h->stage.size(), hipMemcpyHostToDevice, h->own_stream));
     HIP_TRY(hipStreamSynchronize(h->own_stream));         // the staging vector goes away below
-    for (auto &f : h->fixups) *f.second = static_cast<const unsigned char *>(h->arena) + f.first;
+    for (auto &f : h->fixups) *f.second = static_cast<const unsigned char *>(*arena) + f.first;
     h->stage.clear();
     h->stage.shrink_to_fit();
     h->fixups.clear();
@@ -1075,6 +1123,9 @@ static int open_device(int device, ldpc_handle *h)
             h->own_stream = p.stream;
             h->arena = p.arena;
             h->arena_cap = p.cap;
+            DevBuf *mine[POOL_BUFS];
+            scratch_buffers(h, mine);
+            for (int k = 0; k < POOL_BUFS; ++k) *mine[k] = p.bufs[k];
         }
     }
     if (!h->own_stream) HIP_TRY(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
@@ -1101,15 +1152,23 @@ extern "C" void ldpc_destroy(ldpc_handle *h)
     if (h->own_stream && h->device < 64) {
         std::lock_guard<std::mutex> g(g_pool_mutex);
         if (g_pool[h->device].size() < POOL_KEEP) {
-            g_pool[h->device].push_back(PooledParts{h->own_stream, h->arena, h->arena_cap});
+            PooledParts p{h->own_stream, h->arena, h->arena_cap, {}};
+            DevBuf *mine[POOL_BUFS];
+            scratch_buffers(h, mine);
+            for (int k = 0; k < POOL_BUFS; ++k)
+                if (mine[k]->cap <= (size_t)POOL_BUF_MAX) { p.bufs[k] = *mine[k]; *mine[k] = DevBuf(); }
+            g_pool[h->device].push_back(p);
             pooled = true;
         }
     }
     if (pooled) { h->own_stream = nullptr; h->arena = nullptr; }
     if (h->arena) (void)hipFree(h->arena);
-    DevBuf *bufs[] = {&h->b_llr, &h->b_hard, &h->b_iters, &h->b_conv, &h->b_ones, &h->b_soft,
-                      &h->b_sig, &h->b_sq, &h->b_unc, &h->b_cnt, &h->b_pf, &h->b_ws, &h->b_chain32, &h->b_chain64, &h->b_work};
+    if (h->edge_arena) (void)hipFree(h->edge_arena);
+    DevBuf *bufs[POOL_BUFS];
+    scratch_buffers(h, bufs);
     for (DevBuf *b : bufs) b->release();
+    h->b_chain32.release();
+    h->b_chain64.release();
     if (h->copy_stream) { (void)hipStreamSynchronize(h->copy_stream); (void)hipStreamDestroy(h->copy_stream); }
     for (HostSlot &sl : h->slot) {
         DevBuf *sb[] = {&sl.llr, &sl.hard, &sl.iters, &sl.conv, &sl.ones, &sl.soft};
@@ -1150,6 +1209,48 @@ static int build_csr(ldpc_handle *h, const std::vector<int32_t> &rp, const std::
         (rc = upload(h, cp, &h->csr.col_ptr)) || (rc = upload(h, crow, &h->csr.col_row)) ||
         (rc = upload(h, ce, &h->csr.col_e)))
         return rc;
+    h->edges_ready = true;
+    return 0;
+}
+
+// A block-circulant code as an edge list, columns ascending inside a row: staged, not yet on the device.
+static int stage_qc_edges(ldpc_handle *h, const int32_t *blk_ptr, const int32_t *shifts)
+{
+    const int Z = h->qc.Z, mb = h->qc.mb, nb = h->qc.nb;
+    std::vector<int32_t> rp((size_t)h->m + 1, 0), ci;
+    ci.reserve((size_t)h->E);
+    std::vector<int32_t> cols;
+    for (int b = 0; b < mb; ++b)
+        for (int i = 0; i < Z; ++i) {
+            cols.clear();
+            for (int j = 0; j < nb; ++j)
+                for (int k = blk_ptr[b * nb + j]; k < blk_ptr[b * nb + j + 1]; ++k)
+                    cols.push_back(j * Z + (i + shifts[k]) % Z);
+            std::sort(cols.begin(), cols.end());
+            ci.insert(ci.end(), cols.begin(), cols.end());
+            rp[(size_t)b * Z + i + 1] = (int32_t)ci.size();
+        }
+    return build_csr(h, rp, ci, h->m, h->n);
+}
+
+// The edge list on the device, for the kernels that walk it (table-driven min-sum, sum-product outside
+// the message planes, the short-code kernel).  may_allocate false: the caller promised not to allocate.
+static int edge_tables(ldpc_handle *h, bool may_allocate)
+{
+    if (h->edges_ready) return 0;
+    if (!may_allocate)
+        return fail(LDPC_E_UNSUPPORTED, "this handle's edge tables are not on the device yet and building them allocates: "
+                                        "decode once through ldpc_decode_device with the same algorithm and precision first");
+    HIP_TRY(hipSetDevice(h->device));
+    int rc = stage_qc_edges(h, h->qc_blk_ptr.data(), h->qc_shifts.data());
+    if (rc || (rc = commit_tables(h, &h->edge_arena, &h->edge_arena_cap))) {
+        h->edges_ready = false;
+        h->stage.clear();
+        h->fixups.clear();
+        return rc;
+    }
+    h->qc_blk_ptr.clear(); h->qc_blk_ptr.shrink_to_fit();
+    h->qc_shifts.clear(); h->qc_shifts.shrink_to_fit();
     return 0;
 }
 
@@ -1310,27 +1411,27 @@ extern "C" int ldpc_create_qc(int device, int Z, int mb, int nb, const int32_t *
             h->planes_max_w = h_max_w;
         }
     }
-    // the same graph as an edge list, columns ascending inside a row (used by the sum-product kernel)
+    // column and row degrees, which kernel selection looks at
+    h->max_col_deg = 0;
+    for (int j = 0; j < nb; ++j) {
+        int d = 0;
+        for (int b = 0; b < mb; ++b) d += blk_ptr[b * nb + j + 1] - blk_ptr[b * nb + j];
+        h->max_col_deg = std::max(h->max_col_deg, d);
+    }
+    h->min_row_deg = max_deg;
+    for (int b = 0; b < mb; ++b) h->min_row_deg = std::min(h->min_row_deg, blk_ptr[(b + 1) * nb] - blk_ptr[b * nb]);
+    // the same graph as an edge list: now, unless the message-plane kernels take the code (then on first need)
     {
-        std::vector<int32_t> rp((size_t)h->m + 1, 0), ci;
-        ci.reserve((size_t)h->E);
-        std::vector<int32_t> cols;
-        for (int b = 0; b < mb; ++b)
-            for (int i = 0; i < Z; ++i) {
-                cols.clear();
-                for (int j = 0; j < nb; ++j)
-                    for (int k = blk_ptr[b * nb + j]; k < blk_ptr[b * nb + j + 1]; ++k)
-                        cols.push_back(j * Z + (i + shifts[k]) % Z);
-                std::sort(cols.begin(), cols.end());
-                ci.insert(ci.end(), cols.begin(), cols.end());
-                rp[(size_t)b * Z + i + 1] = (int32_t)ci.size();
-            }
-        if ((rc = build_csr(h, rp, ci, h->m, h->n))) {
+        const char *eager = hook("LDPC_HIP_EAGER_EDGES");
+        if (h->planes_ok && !(eager && eager[0] == '1')) {
+            h->qc_blk_ptr.assign(blk_ptr, blk_ptr + nblk + 1);
+            h->qc_shifts.assign(shifts, shifts + blk_ptr[nblk]);
+        } else if ((rc = stage_qc_edges(h, blk_ptr, shifts))) {
             ldpc_destroy(h);
             return rc;
         }
     }
-    if ((rc = commit_tables(h))) { ldpc_destroy(h); return rc; }
+    if ((rc = commit_tables(h, &h->arena, &h->arena_cap))) { ldpc_destroy(h); return rc; }
     *out = h;
     return 0;
 }
@@ -1363,7 +1464,7 @@ extern "C" int ldpc_create_csr(int device, int m, int n, const int32_t *row_ptr,
     if (rc) { delete h; return rc; }
     h->is_qc = false;
     h->m = m; h->n = n; h->E = E; h->max_row_deg = max_deg;
-    if ((rc = build_csr(h, rp, ci, m, n)) || (rc = commit_tables(h))) {
+    if ((rc = build_csr(h, rp, ci, m, n)) || (rc = commit_tables(h, &h->arena, &h->arena_cap))) {
         ldpc_destroy(h);
         return rc;
     }
@@ -1769,6 +1870,7 @@ static int launch_decode(ldpc_handle *h, int algo, int prec, const DecodeArgs &a
     }
     DecodeArgs a = args;
     a.pass_counts = h->pass_counts;
+    if ((L.slots || L.csr || (algo == LDPC_ALGO_SUMPRODUCT && !L.planes)) && (rc = edge_tables(h, fixed == nullptr))) return rc;
     if (L.slots) {
         SlotTables tb;
         tb.m = h->m; tb.n = h->n; tb.E = h->E; tb.F = L.fpw;
@@ -2088,8 +2190,15 @@ extern "C" int ldpc_eval_awgn(ldpc_handle *h, int algo, int prec, int sign_mode,
     if ((rc = select_launch(h, algo, prec, frames_per_snr, false, &L))) return rc;
     const char *unfused = hook("LDPC_HIP_NO_FUSED_CHANNEL");
     const bool fused = L.fn_gen != nullptr && !(unfused && unfused[0] == '1');
+    // A small sweep (the gym's 3 points x a few frames, ldpc_env.py:353-377) goes out as ONE launch: a point's
+    // time is that of its slowest frame, and with most of the card idle the points can run side by side.
+    // Same noise per (point, frame) as one launch per point (LDPC_HIP_NO_POINT_BATCH=1, a test hook).
+    const char *unbatched = hook("LDPC_HIP_NO_POINT_BATCH");
+    const bool batched = fused && n_snr > 1 && n_snr <= GEN_MAX_POINTS && frames_per_snr * n_snr <= GEN_MAX_BATCH &&
+                         !(unbatched && unbatched[0] == '1');
     const int64_t cap = fused ? ((int64_t)1 << 24) : (int64_t)(((size_t)8192 << 20) / (n * 4)) + 1;
-    const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(frames_per_snr, cap));
+    const int64_t chunk = batched ? frames_per_snr * n_snr : std::max<int64_t>(1, std::min<int64_t>(frames_per_snr, cap));
+    if (batched && (rc = select_launch(h, algo, prec, chunk, false, &L))) return rc;      // grid for all the points' frames
     if ((rc = h->b_iters.ensure((size_t)chunk * 4)) ||
         (rc = h->b_conv.ensure((size_t)chunk)) || (rc = h->b_ones.ensure((size_t)chunk * 4)) ||
         (rc = h->b_unc.ensure((size_t)chunk * 4)) ||
@@ -2100,9 +2209,10 @@ extern "C" int ldpc_eval_awgn(ldpc_handle *h, int algo, int prec, int sign_mode,
         return rc;
     if (per_frame && (rc = h->b_pf.ensure((size_t)chunk * 16))) return rc;
     HIP_TRY(hipMemsetAsync(h->b_cnt.p, 0, sizeof(uint64_t) * 6 * (size_t)n_snr, h->stream));
-    for (int s = 0; s < n_snr; ++s) {
-        for (int64_t f0 = 0; f0 < frames_per_snr; f0 += chunk) {
-            const int64_t nf = std::min<int64_t>(chunk, frames_per_snr - f0);
+    const int n_launch_points = batched ? 1 : n_snr;
+    for (int s = 0; s < n_launch_points; ++s) {
+        for (int64_t f0 = 0; f0 < (batched ? chunk : frames_per_snr); f0 += chunk) {
+            const int64_t nf = batched ? chunk : std::min<int64_t>(chunk, frames_per_snr - f0);
             DecodeArgs a;
             a.llr_f64 = 0; a.n_frames = nf;
             // min-sum works on the raw channel values like the reference (ldpc.py:371-377: no scaling);
@@ -2113,12 +2223,20 @@ extern "C" int ldpc_eval_awgn(ldpc_handle *h, int algo, int prec, int sign_mode,
             a.conv = reinterpret_cast<uint8_t *>(h->b_conv.p);
             a.ones = reinterpret_cast<int32_t *>(h->b_ones.p);
             a.soft = nullptr; a.chain = nullptr; a.work = nullptr; a.ms_alpha = h->ms_alpha; a.ms_beta = h->ms_beta; a.precheck = precheck_override();
+            PointSigmas ps{};
             if (fused) {
                 a.llr = nullptr;
                 a.gen_seed = seed; a.gen_stream = (uint32_t)s; a.gen_first_frame = first_frame + (uint64_t)f0;
                 a.gen_sigma = (float)sqrt(0.5 / pow(10.0, snr_db[s] / 10.0));      // ldpc.py:53-55
                 a.gen_uncoded = reinterpret_cast<int32_t *>(h->b_unc.p);
                 a.gen_sumsq = reinterpret_cast<unsigned long long *>(h->b_sq.p);
+                if (batched) {
+                    a.gen_per_point = (uint32_t)frames_per_snr;
+                    for (int q = 0; q < n_snr; ++q) {
+                        a.gen_point_sigma[q] = ps.sigma[q] = (float)sqrt(0.5 / pow(10.0, snr_db[q] / 10.0));
+                        a.gen_point_scale[q] = algo == LDPC_ALGO_SUMPRODUCT ? (float)(4.0 * pow(10.0, snr_db[q] / 10.0)) : 1.0f;
+                    }
+                }
             } else {
                 if ((rc = launch_channel(h, snr_db[s], seed, (uint32_t)s, first_frame + (uint64_t)f0, nf,
                                          reinterpret_cast<float *>(h->b_llr.p),
@@ -2138,7 +2256,8 @@ extern "C" int ldpc_eval_awgn(ldpc_handle *h, int algo, int prec, int sign_mode,
                                fused ? nullptr : reinterpret_cast<const float *>(h->b_sig.p),
                                fused ? reinterpret_cast<const unsigned long long *>(h->b_sq.p) : nullptr,
                                reinterpret_cast<unsigned long long *>(h->b_cnt.p) + 6 * s,
-                               per_frame ? reinterpret_cast<float *>(h->b_pf.p) : nullptr);
+                               per_frame ? reinterpret_cast<float *>(h->b_pf.p) : nullptr,
+                               a.gen_per_point, ps);
             HIP_TRY(hipGetLastError());
             if (per_frame)
                 HIP_TRY(hipMemcpyAsync(per_frame + ((size_t)s * frames_per_snr + f0) * 4, h->b_pf.p,

@@ -643,18 +643,28 @@ planes_role(unsigned char *smem, const PlanesTables &tb, const DecodeArgs &a)
     auto generate_frame = [&](int64_t frame) {
         uint32_t sq = 0;                 // this thread's 8 samples: < 2^28 in 2^-19 fixed point
         int err = 0;                     // wave-uniform: channel hard-decision errors of the wave
+        unsigned long long noise_frame = a.gen_first_frame + (uint64_t)frame;
+        uint32_t noise_stream = a.gen_stream;
+        float sigma = a.gen_sigma, scale = a.llr_scale;
+        if (a.gen_per_point) {           // several sweep points in this launch (at most GEN_MAX_BATCH frames in all)
+            const uint32_t pt = (uint32_t)frame / a.gen_per_point;
+            noise_frame = a.gen_first_frame + (uint64_t)((uint32_t)frame - pt * a.gen_per_point);
+            noise_stream += pt;
+            sigma = a.gen_point_sigma[pt];
+            scale = a.gen_point_scale[pt];
+        }
 #pragma unroll
         for (int hh = 0; hh < (N / 4 + NT - 1) / NT; ++hh) {
             const uint32_t qb = (uint32_t)tid + (uint32_t)hh * NT;
             if (qb < (uint32_t)(N / 4)) {
-                const float4 z = normal4(a.gen_seed, a.gen_first_frame + (uint64_t)frame, qb, a.gen_stream);
+                const float4 z = normal4(a.gen_seed, noise_frame, qb, noise_stream);
                 const float zz[4] = {z.x, z.y, z.z, z.w};
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const float yv = -1.0f + a.gen_sigma * zz[k];
+                    const float yv = -1.0f + sigma * zz[k];
                     sq += awgn_sq_fixed(zz[k]);
                     err += (int)__popcll(__ballot(yv > 0.f));
-                    lds_put_f32(smem, (4u * qb + (uint32_t)k) * CB, yv * a.llr_scale + 0.0f);
+                    lds_put_f32(smem, (4u * qb + (uint32_t)k) * CB, yv * scale + 0.0f);
                 }
             }
         }

@@ -564,6 +564,66 @@ def test_fused_channel_sweep_equals_unfused(engines, monkeypatch, name):
     assert np.allclose(p1[1, :, 0], sigma, rtol=0.05) and p1[1, :, 0].std() > 0
 
 
+def test_small_sweep_in_one_launch_equals_one_launch_per_point(monkeypatch):
+    """A sweep of at most 8 points and 8192 frames in all goes out as one launch (the points' frames side by
+    side); LDPC_HIP_NO_POINT_BATCH=1 launches point after point.  Same noise per (point, frame): counters
+    and per-frame columns identical, for min-sum and sum-product, on the regular and on a heavy code."""
+    import ldpc_amd
+    from ldpc_amd import codes
+    base = codes.near_earth()
+    for code in (base, base.with_block(1, 4, [3, 77, 200, 401, 500])):
+        with ldpc_amd.Decoder(code) as eng:
+            for algo in (0, 1):
+                for snrs, F, first in (([3.0, 3.2, 3.4], 10, 0), ([2.5, 3.0, 3.5, 4.0, 4.5, 5.0, 5.5, 6.0], 1024, 999),
+                                       ([3.1, 3.6], 1, 7)):
+                    monkeypatch.delenv('LDPC_HIP_NO_POINT_BATCH', raising=False)
+                    c1, p1 = eng.eval_awgn(snrs, F, seed=11, first_frame=first, per_frame=True, algo=algo, sign_mode=1)
+                    monkeypatch.setenv('LDPC_HIP_NO_POINT_BATCH', '1')
+                    c2, p2 = eng.eval_awgn(snrs, F, seed=11, first_frame=first, per_frame=True, algo=algo, sign_mode=1)
+                    monkeypatch.delenv('LDPC_HIP_NO_POINT_BATCH')
+                    assert np.array_equal(c1, c2), (algo, snrs, c1, c2)
+                    assert np.array_equal(p1, p2)
+                    assert (c1[:, 0] == F).all()
+            # without per-frame output, and a sweep too large to batch
+            c1, _ = eng.eval_awgn([3.0, 3.4], 300, seed=2)
+            c3, _ = eng.eval_awgn([3.4], 300, seed=2)
+            assert c1[1, 0] == 300 and c1[0, 4] > c1[1, 4]
+            c4, _ = eng.eval_awgn([3.0, 3.4], 5000, seed=2)
+            assert (c4[:, 0] == 5000).all()
+
+
+def test_edge_tables_are_built_on_first_need(oracle_mod, monkeypatch):
+    """A code the message-plane kernels take gets its edge list only when a kernel that walks it is chosen
+    (float64 sum-product here): the results are those of a handle that built it at creation
+    (LDPC_HIP_EAGER_EDGES=1), and the allocation-free entry point says what to do instead of allocating."""
+    import torch
+    import ldpc_amd
+    from ldpc_amd import codes
+    code = codes.near_earth().with_block(0, 6, [5, 90, 300])
+    prng = np.random.RandomState(8)
+    Y = (-1 + 0.47 * prng.normal(size=(24, code.n))).astype(np.float32)
+    outs = []
+    for eager in ('1', None):
+        if eager:
+            monkeypatch.setenv('LDPC_HIP_EAGER_EDGES', eager)
+        else:
+            monkeypatch.delenv('LDPC_HIP_EAGER_EDGES', raising=False)
+        with ldpc_amd.Decoder(code) as eng:
+            a = eng.decode(Y, 20, prec=32, sign_mode=1)                       # message planes: no edge list needed
+            if not eager:
+                d = torch.from_numpy(Y).cuda()
+                hard = torch.empty((24, eng.nbytes), dtype=torch.uint8, device='cuda')
+                with pytest.raises(ldpc_amd.LdpcHipError, match='edge tables'):
+                    eng.decode_device(d, 24, 20, prec=64, algo=ldpc_amd.ALGO_SUMPRODUCT, llr_scale=8.0, d_hard=hard, noalloc=True)
+            b = eng.decode(Y * 8.0, 20, prec=64, algo=ldpc_amd.ALGO_SUMPRODUCT, sign_mode=1)
+            c = eng.decode(Y, 20, prec=32, sign_mode=1)
+            outs.append((a, b, c))
+    for x, y in zip(outs[0], outs[1]):
+        assert np.array_equal(x['hard'], y['hard']) and np.array_equal(x['iters'], y['iters']) and np.array_equal(x['converged'], y['converged'])
+    assert np.array_equal(outs[1][0]['hard'], outs[1][2]['hard'])
+    assert outs[1][1]['iters'].max() > 1
+
+
 def test_heavy_circulants_on_the_message_plane_kernel(oracle_mod, monkeypatch):
     """Circulants of weight 3..8 (what a gym action with up to 7 hot bits installs, ldpc_env.py:293-317):
     float32 stays on the message-plane kernel, the shifts beyond a block's two lowest as extra edges

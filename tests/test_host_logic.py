@@ -146,6 +146,41 @@ def test_recursive_linear_fit():
     assert np.allclose(p, np.polyfit(snr, ber, 1))
 
 
+def test_recursive_linear_fit_shortcut_is_exact():
+    """The fit stops re-fitting once a round drops no point; the plain ten-round loop of common.py:293-303
+    gives the same arrays, coefficients and round count."""
+    import warnings
+    from ldpc_amd import common
+
+    def plain(xData, yData, rounds=10):
+        ber, snr, itr = np.array(yData, copy=True), np.array(xData, copy=True), 0
+        while itr < rounds:
+            p = np.polyfit(snr, ber, 1)
+            t = np.poly1d(p)
+            ber, snr = ber[t(snr) > 0], snr[t(snr) > 0]
+            itr += 1
+        return snr, ber, p, itr
+
+    prng = np.random.RandomState(3)
+    compared = 0
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        for _ in range(300):
+            x = np.repeat([3.0, 3.2, 3.4], 10) + prng.normal(0, 0.01, 30)
+            y = np.maximum(prng.normal(0.02 - 0.15 * (x - 3.0) * prng.rand(), 0.01), 0) * (prng.rand(30) > prng.rand())
+            try:
+                want = plain(x, y)
+            except Exception as e:
+                with pytest.raises(type(e)):
+                    common.recursiveLinearFit(x, y)
+                continue
+            got = common.recursiveLinearFit(x, y)
+            assert np.array_equal(want[0], got[0]) and np.array_equal(want[1], got[1])
+            assert np.array_equal(want[2], got[2]) and want[3] == got[4]
+            compared += 1
+    assert compared > 200
+
+
 def test_engine_cache_never_closes_an_engine_in_use(monkeypatch):
     """The cache of ldpc_amd.ldpc (one engine per (device, code)) evicts least recently used engines,
     but never one that a caller still holds; an engine dropped while in use is closed by its last user."""
