@@ -223,6 +223,28 @@ int ldpc_eval_awgn(ldpc_handle *h, int algo, int prec, int sign_mode, int max_it
                    uint64_t seed, uint64_t first_frame, uint64_t *counters,
                    float *per_frame);
 
+/*
+ * The path's one exchange step for callers that have no collective of their own: the error
+ * counters of the ranks' shares of a sweep, summed over RCCL (one process per GPU).  The
+ * reference adds up its devices' berStatistics on the host after its process pool returns
+ * (ldpcCUDA.py:897-912); a Python caller of this package uses torch.distributed instead.
+ * RCCL is opened when the first of these calls is made (the copy a framework in the process
+ * already loaded, else the system's); without it they return LDPC_E_UNSUPPORTED.
+ *   ldpc_comm_unique_id   rank 0 fills id_out [LDPC_COMM_ID_BYTES] and hands the bytes to every
+ *                         rank by the caller's own means (file, socket, launcher)
+ *   ldpc_comm_create      collective over all `world` ranks: every rank calls it with the same id,
+ *                         its own rank and the GPU it decodes on (one rank per GPU)
+ *   ldpc_allreduce_counters  collective: counters [count] (host, e.g. ldpc_eval_awgn's
+ *                         [n_snr][6]) are replaced by their sums over the ranks.  Synchronous.
+ * A communicator is not thread-safe; distinct ones are.
+ */
+#define LDPC_COMM_ID_BYTES 128
+typedef struct ldpc_comm ldpc_comm;
+int ldpc_comm_unique_id(void *id_out);
+int ldpc_comm_create(int device, int rank, int world, const void *id, ldpc_comm **out);
+int ldpc_allreduce_counters(ldpc_comm *comm, uint64_t *counters, int count);
+void ldpc_comm_destroy(ldpc_comm *comm);
+
 /* Launch geometry the decoder uses for (algo, prec): workgroups, threads per
  * workgroup, dynamic LDS bytes, frames per workgroup.  For reports. */
 int ldpc_get_launch_info(ldpc_handle *h, int algo, int prec, int *grid, int *block,

@@ -11,6 +11,7 @@ SYMBOLS = (
     'ldpc_get_dims', 'ldpc_set_minsum_scaling', 'ldpc_set_pass_counters', 'ldpc_set_stream', 'ldpc_sync', 'ldpc_decode', 'ldpc_decode_chained',
     'ldpc_reset_state', 'ldpc_decode_device', 'ldpc_decode_device_noalloc',
     'ldpc_channel_awgn_device', 'ldpc_eval_awgn', 'ldpc_get_launch_info',
+    'ldpc_comm_unique_id', 'ldpc_comm_create', 'ldpc_comm_destroy', 'ldpc_allreduce_counters',
 )
 
 _lib = None
@@ -97,5 +98,13 @@ def load():
     L.ldpc_get_launch_info.restype = i32
     L.ldpc_get_launch_info.argtypes = [vp, i32, i32, c.POINTER(i32), c.POINTER(i32), c.POINTER(i32),
                                        c.POINTER(i32)]
+    L.ldpc_comm_unique_id.restype = i32
+    L.ldpc_comm_unique_id.argtypes = [vp]
+    L.ldpc_comm_create.restype = i32
+    L.ldpc_comm_create.argtypes = [i32, i32, i32, vp, c.POINTER(vp)]
+    L.ldpc_comm_destroy.restype = None
+    L.ldpc_comm_destroy.argtypes = [vp]
+    L.ldpc_allreduce_counters.restype = i32
+    L.ldpc_allreduce_counters.argtypes = [vp, vp, i32]
     _lib = L
     return L

@@ -56,6 +56,12 @@ static int fail(int code, const char *fmt, ...)
     return code;
 }
 
+// for the library's other source file (comm.hip); not part of the C ABI
+extern "C" __attribute__((visibility("hidden"))) void ldpc_set_error_(const char *text)
+{
+    snprintf(g_err, sizeof(g_err), "%s", text);
+}
+
 #define HIP_TRY(expr)                                                              \
     do {                                                                           \
         hipError_t e_ = (expr);                                                    \

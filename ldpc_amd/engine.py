@@ -45,6 +45,52 @@ def _ptr(x):
     raise TypeError(f'cannot take a device pointer from {type(x)!r}')
 
 
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """bytes [128] that rank 0 hands to every rank before Comm(...) (ldpc_comm_unique_id)."""
+    buf = ctypes.create_string_buffer(COMM_ID_BYTES)
+    _check(_lib.load().ldpc_comm_unique_id(buf))
+    return buf.raw
+
+
+class Comm:
+    """The C library's own RCCL communicator (one rank per GPU), for callers without torch.distributed:
+    allreduce(counters) replaces a uint64 array by its sum over the ranks."""
+
+    def __init__(self, device, rank, world, unique_id):
+        if len(unique_id) != COMM_ID_BYTES:
+            raise ValueError(f'unique_id must be {COMM_ID_BYTES} bytes')
+        self._L = _lib.load()
+        self._c = ctypes.c_void_p()
+        _check(self._L.ldpc_comm_create(int(device), int(rank), int(world), ctypes.c_char_p(bytes(unique_id)),
+                                        ctypes.byref(self._c)))
+        self.rank, self.world = int(rank), int(world)
+
+    def allreduce(self, counters):
+        c = np.ascontiguousarray(counters, dtype=np.uint64)
+        _check(self._L.ldpc_allreduce_counters(self._c, c.ctypes.data, int(c.size)))
+        return c
+
+    def close(self):
+        if getattr(self, '_c', None) is not None and self._c:
+            self._L.ldpc_comm_destroy(self._c)
+            self._c = ctypes.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Decoder:
     """LDPC decoder / code evaluator on one HIP device.
 

@@ -190,3 +190,37 @@ def test_device_noise_curve_within_monte_carlo_interval_of_the_oracle(oracle_mod
         b, blo, bhi = common.ber_interval(e_g, qc.n)
         assert blo <= b <= bhi and b == ber_g
     assert (pf[0, :, 2] > 0).mean() > 0.5 > (pf[2, :, 2] > 0).mean()       # the points straddle the waterfall
+
+
+@pytest.mark.gpu
+def test_library_communicator_single_rank():
+    """ldpc_comm_* / ldpc_allreduce_counters over RCCL with one rank: the id round trip, the collective
+    (a sum over one rank leaves the counters as they are, whatever their number) and teardown.  More ranks need
+    more cards than this test's box has; RCCL refuses two ranks on one GPU."""
+    import ldpc_amd
+    from ldpc_amd import codes
+    ident = ldpc_amd.comm_unique_id()
+    assert len(ident) == 128 and any(ident)
+    with ldpc_amd.Comm(0, 0, 1, ident) as comm, ldpc_amd.Decoder(codes.near_earth()) as eng:
+        cnt, _ = eng.eval_awgn([3.0, 3.5], 200, seed=4)
+        total = comm.allreduce(cnt)
+        assert total.shape == cnt.shape and np.array_equal(total, cnt)
+        big = np.arange(1000, dtype=np.uint64) * np.uint64(1 << 40)
+        assert np.array_equal(comm.allreduce(big), big)
+    with pytest.raises(ldpc_amd.LdpcHipError):
+        ldpc_amd.Comm(0, 1, 1, ident)
+
+
+@pytest.mark.gpu
+def test_library_communicator_two_ranks():
+    """Two processes, one GPU each, sum their shares of a sweep through ldpc_allreduce_counters
+    (tools/comm_two_ranks.py): the sum equals one rank decoding all the frames.  Needs two cards."""
+    import subprocess
+    import sys
+    import ldpc_amd
+    if ldpc_amd.device_count() < 2:
+        pytest.skip('one rank per GPU: needs two cards')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'comm_two_ranks.py'), '2'],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and 'OK' in r.stdout, r.stdout + r.stderr

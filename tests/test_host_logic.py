@@ -48,6 +48,14 @@ def test_argument_errors_do_not_need_a_device():
     assert L.ldpc_create_csr(0, 2, 4, rp.ctypes.data, sh.ctypes.data, ctypes.byref(h)) == -1
     assert L.ldpc_decode(None, 0, 32, 0, 50, 1, None, 32, None, None, None, None, None) == -1
     assert L.ldpc_sync(None) == -1
+    # the counters' all-reduce: argument checks come before RCCL or a device is looked for
+    c = ctypes.c_void_p()
+    ident = ctypes.create_string_buffer(128)
+    assert L.ldpc_comm_create(0, 2, 2, ident, ctypes.byref(c)) == -1 and b'rank' in L.ldpc_last_error()
+    assert L.ldpc_comm_create(0, 0, 1, None, ctypes.byref(c)) == -1
+    assert L.ldpc_comm_unique_id(None) == -1
+    assert L.ldpc_allreduce_counters(None, None, 0) == -1
+    L.ldpc_comm_destroy(None)
 
 
 def test_code_tables_and_conversions():
