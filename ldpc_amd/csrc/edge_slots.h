@@ -34,6 +34,8 @@ struct SlotTables {
     const int32_t *col_idx;    // [E] ascending inside a row
     const int32_t *edge_slot;  // [E] rank of the edge's row among the rows of its column
     const int32_t *col_ptr;    // [n+1] (column degrees)
+    const int32_t *col_rec;    // [n] first word of a column's record, edge_packed.h
+    int rec_words;             // words of a frame's records, edge_packed.h
 };
 
 struct SlotGeom {

@@ -497,6 +497,7 @@ qc_minsum_kernel(const QcTables tb, const DecodeArgs a)
 #include "qc_regular.h"
 #include "qc_planes.h"
 #include "edge_slots.h"
+#include "edge_packed.h"
 
 // ---------------------------------------------------------------- CSR min-sum kernel
 //
@@ -968,7 +969,8 @@ struct Launch {
     size_t lds = 0;
     bool spa_lds = false;     // sum-product: posteriors and messages in LDS (else in the workspace)
     bool spa_planes = false;  // sum-product on the message-plane kernel
-    bool slots = false;       // short-code kernel on the edge list (edge_slots.h)
+    bool slots = false;       // short-code kernel on the edge list (edge_slots.h, edge_packed.h)
+    bool packed = false;      // ... the one with records of the columns' own length (edge_packed.h)
     bool planes = false;      // message-plane kernel (qc_planes.h)
     bool csr = false;         // csr_minsum_kernel (state in a global workspace)
     int max_grid = 1;         // workgroups that are resident at once
@@ -1000,6 +1002,8 @@ struct ldpc_handle {
     // CSR
     CsrTables csr{};
     const int32_t *edge_slot = nullptr;   // [E] rank of each edge's row inside its column
+    const int32_t *col_rec = nullptr;     // [n] first word of each column's record in a frame of edge_packed.h
+    int rec_words = 0;                    // words of all the records of a frame
     int max_col_deg = 0, min_row_deg = 0;
     // the code's tables: staged on the host while the handle is built, then ONE device allocation
     // (taken from the per-device pool when a destroyed handle left one that is large enough)
@@ -1209,7 +1213,18 @@ static int build_csr(ldpc_handle *h, const std::vector<int32_t> &rp, const std::
     for (int c = 0; c < n; ++c) h->max_col_deg = std::max(h->max_col_deg, cp[c + 1] - cp[c]);
     h->min_row_deg = m > 0 ? rp[1] - rp[0] : 0;
     for (int r = 0; r < m; ++r) h->min_row_deg = std::min(h->min_row_deg, rp[r + 1] - rp[r]);
+    // records of edge_packed.h: posterior + one word per check, padded to an odd number of words (columns
+    // of a circulant have equal degrees, so neighbouring lanes are one record apart: an even stride would
+    // put them on half or a quarter of the LDS banks)
+    std::vector<int32_t> crec(n);
+    int words = 0;
+    for (int c = 0; c < n; ++c) {
+        crec[c] = words;
+        words += (1 + (cp[c + 1] - cp[c])) | 1;
+    }
+    h->rec_words = words;
     int rc;
+    if ((rc = upload(h, crec, &h->col_rec))) return rc;
     if ((rc = upload(h, eslot, &h->edge_slot))) return rc;
     if ((rc = upload(h, rp, &h->csr.row_ptr)) || (rc = upload(h, ci, &h->csr.col_idx)) ||
         (rc = upload(h, cp, &h->csr.col_ptr)) || (rc = upload(h, crow, &h->csr.col_row)) ||
@@ -1687,6 +1702,57 @@ static int slots_pick(const ldpc_handle *h, bool spa, Launch *L)
     return 0;
 }
 
+// Short codes of low row degree, float32 min-sum: records of the columns' own length, several frames per
+// thread (edge_packed.h).  The plan: as many frames in LDS as fit, G groups of threads x RPT frames each.
+struct PackedPlan { int F = 0, rpt = 0, block = 0; const void *fn = nullptr; size_t lds = 0; };
+
+static const void *packed_fn(int d, int rpt)
+{
+#define PACKED_ROW(DCV)                                                                                   \
+    (rpt == 2   ? reinterpret_cast<const void *>(&packed_minsum_kernel<DCV, 2>)                          \
+     : rpt == 4 ? reinterpret_cast<const void *>(&packed_minsum_kernel<DCV, 4>) : nullptr)
+    return d <= 8 ? PACKED_ROW(8) : d <= 12 ? PACKED_ROW(12) : d <= 16 ? PACKED_ROW(16) : d <= 20 ? PACKED_ROW(20)
+           : d <= 24 ? PACKED_ROW(24) : nullptr;
+#undef PACKED_ROW
+}
+
+static PackedPlan packed_plan(const ldpc_handle *h)
+{
+    PackedPlan best;
+    if (!h->edges_ready || h->m <= 0 || h->m > 1024 || h->max_col_deg > 12 || h->min_row_deg < 2 || h->max_row_deg > 24) return best;
+    const char *force = hook("LDPC_HIP_PACKED_RPT");
+    for (int rpt : {2, 4}) {
+        if (force && force[0] && atoi(force) != rpt) continue;
+        for (int g = 1024 / h->m; g >= 1; --g) {
+            const int F = g * rpt;
+            if (F > 32) continue;
+            const PackedGeom geo(h->rec_words, F, rpt);
+            if (geo.bytes > h->lds_max) continue;
+            const int per_thread = PackedGeom::YTOT / rpt;             // columns a thread can hold
+            const int need_cols = (g * h->n + per_thread - 1) / per_thread;
+            const int block = (std::max(g * h->m, need_cols) + 63) / 64 * 64;
+            if (block > 1024) continue;
+            if (F > best.F) {                      // most frames in flight; of equal plans the one with more row threads (the narrower groups)
+                best.F = F; best.rpt = rpt; best.block = block; best.lds = geo.bytes;
+                best.fn = packed_fn(h->max_row_deg, rpt);
+            }
+            break;                                 // smaller g only lowers F for this rpt
+        }
+    }
+    if (!best.fn) best = PackedPlan();
+    return best;
+}
+
+static bool packed_applies(const ldpc_handle *h, int prec, bool chained)
+{
+    const char *off = hook("LDPC_HIP_NO_PACKED"), *off2 = hook("LDPC_HIP_NO_SLOTS");
+    if (prec != 32 || chained || (off && off[0] == '1') || (off2 && off2[0] == '1')) return false;
+    // worth it where the other short-code kernel cannot keep a compute unit busy: fewer than half the frames per workgroup
+    const int F = packed_plan(h).F;
+    const char *force = hook("LDPC_HIP_PACKED_RPT");
+    return F >= 2 && ((force && force[0]) || !slots_applies(h, prec, chained) || F >= 2 * slots_frames(h));
+}
+
 // Workgroups of `fn` that fit a CU: one attribute call and one occupancy query per
 // (device, kernel, geometry) and process, not per decode call.
 static int blocks_per_cu(int device, const void *fn, int block, size_t lds, int *out, bool needs_lds_at_zero = false)
@@ -1752,6 +1818,15 @@ static int select_kernel(ldpc_handle *h, int algo, int prec, bool chained, Launc
         if (rc) return rc;
         L->max_grid = h->n_cu * per_cu;
         L->ws_stride = L->spa_lds ? 0 : ((spa_state_bytes(h, prec) + 255) & ~(size_t)255);
+        return 0;
+    }
+    if (!(h->is_qc && planes_applies(h, prec, chained)) && packed_applies(h, prec, chained)) {
+        const PackedPlan pl = packed_plan(h);
+        L->fn = pl.fn; L->fpw = pl.F; L->block = pl.block; L->lds = pl.lds;
+        L->slots = true; L->packed = true;
+        int rc = blocks_per_cu(h->device, L->fn, L->block, L->lds, &per_cu, true);
+        if (rc) return rc;
+        L->max_grid = h->n_cu * per_cu;
         return 0;
     }
     if (!(h->is_qc && planes_applies(h, prec, chained)) && slots_applies(h, prec, chained)) {
@@ -1881,6 +1956,7 @@ static int launch_decode(ldpc_handle *h, int algo, int prec, const DecodeArgs &a
         SlotTables tb;
         tb.m = h->m; tb.n = h->n; tb.E = h->E; tb.F = L.fpw;
         tb.row_ptr = h->csr.row_ptr; tb.col_idx = h->csr.col_idx; tb.edge_slot = h->edge_slot; tb.col_ptr = h->csr.col_ptr;
+        tb.col_rec = h->col_rec; tb.rec_words = h->rec_words;
         if ((rc = claim_counter(h, L, &a, fixed))) return rc;
         void *kargs[] = {&tb, &a};
         HIP_TRY(hipLaunchKernel(L.fn, dim3(L.grid), dim3(L.block), kargs, L.lds, h->stream));
