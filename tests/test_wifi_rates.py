@@ -118,3 +118,76 @@ def test_gpu_bit_exact_against_oracle(oracle_mod, rate):
         # sweep driver on the same kernels
         cnt, _ = eng.eval_awgn([SNR[rate][-1]], 2000, seed=5, sign_mode=1)
         assert cnt[0, 0] == 2000 and cnt[0, 1] < 200
+
+
+@pytest.mark.gpu
+def test_interleaved_frames_kernel(oracle_mod, monkeypatch):
+    """Rates 1/2 ... 3/4 keep one or two frames per workgroup on the short-code kernel with fixed-size column
+    records; the kernel with records of the columns' own length, frames interleaved in groups of 2 or 4 (one
+    LDS access per edge for the whole group), holds four.  It is selected where it at least doubles the frames
+    per workgroup, gives the results of the other kernel and of the oracle bit for bit -- min-sum with either
+    sign rule and normalised/offset scaling, soft output, float64 input, frame counts that leave groups and
+    blocks partly empty, frames that never converge beside ones that stop at once -- and so do both group
+    widths on codes of other shapes (a frame length that is no multiple of 8 takes the byte-wise output path)."""
+    import ldpc_amd
+    from ldpc_amd import codes
+    for rate, expect in (('1/2', 4), ('2/3', 4), ('3/4', 4), ('5/6', 3)):
+        qc = codes.wifi_1944(rate)
+        with ldpc_amd.Decoder(qc) as eng:
+            monkeypatch.delenv('LDPC_HIP_NO_PACKED', raising=False)
+            info = eng.launch_info(prec=32)
+            assert info['frames_per_wg'] == expect, (rate, info)
+            if rate == '5/6':
+                continue
+            orc = oracle_mod.Oracle(qc.to_dense())
+            for F, snr in ((1, 2.0), (3, 1.0), (4, 2.5), (5, 0.0), (37, 1.5), (1031, 2.0)):
+                Y = make_llrs(7 * F + 1, snr, qc.n, F)
+                if F >= 5:
+                    Y[1] = np.float32(-1.0)                  # a codeword at once, beside frames that run long
+                    Y[4, ::3] = 0.0
+                for sm in (1, 0):
+                    monkeypatch.delenv('LDPC_HIP_NO_PACKED', raising=False)
+                    a = eng.decode(Y, 20, prec=32, sign_mode=sm, want_soft=True)
+                    monkeypatch.setenv('LDPC_HIP_NO_PACKED', '1')
+                    assert eng.launch_info(prec=32)['frames_per_wg'] < expect
+                    b = eng.decode(Y, 20, prec=32, sign_mode=sm, want_soft=True)
+                    for key in ('hard', 'iters', 'converged', 'ones', 'soft'):
+                        assert np.array_equal(a[key], b[key]), (rate, F, sm, key)
+                    if F <= 37:
+                        hard, iters, conv, soft = orc.minsum(Y, 20, prec=32, sign_mode=sm, threads=8)
+                        assert np.array_equal(a['iters'], iters) and np.array_equal(a['hard'], hard)
+                        assert np.array_equal(a['converged'], conv) and np.array_equal(a['soft'], soft)
+            monkeypatch.delenv('LDPC_HIP_NO_PACKED', raising=False)
+            # float64 channel values into the float32 kernel, and normalised min-sum
+            Y = make_llrs(99, 1.5, qc.n, 9)
+            a = eng.decode(Y.astype(np.float64), 20, prec=32, sign_mode=1)
+            b = eng.decode(Y, 20, prec=32, sign_mode=1)
+            assert np.array_equal(a['iters'], b['iters']) and np.array_equal(a['hard'], b['hard'])
+            eng.set_minsum_scaling(0.8125, 0.0)
+            a = eng.decode(Y, 20, prec=32, sign_mode=1)
+            hard, iters, conv, _ = orc.minsum(Y, 20, prec=32, sign_mode=1, alpha=0.8125, beta=0.0, want_soft=False, threads=8)
+            assert np.array_equal(a['iters'], iters) and np.array_equal(a['hard'], hard)
+    # other shapes: random sparse matrices, both group widths forced
+    prng = np.random.RandomState(77)
+    for (m, n, dv) in ((40, 100, 3), (97, 203, 4), (250, 504, 3)):
+        H = np.zeros((m, n), np.int32)
+        for c in range(n):
+            H[prng.choice(m, dv, replace=False), c] = 1
+        for r in range(m):                                   # every row at least 2 ones
+            while H[r].sum() < 2:
+                H[r, prng.randint(n)] = 1
+        if H.sum(1).max() > 24 or H.sum(0).max() > 12:
+            continue
+        orc = oracle_mod.Oracle(H)
+        Y = make_llrs(m, 3.0, n, 77)
+        hard, iters, conv, soft = orc.minsum(Y, 15, prec=32, sign_mode=1, threads=8)
+        with ldpc_amd.Decoder(H) as eng:
+            for rpt in ('2', '4'):
+                monkeypatch.setenv('LDPC_HIP_PACKED_RPT', rpt)
+                info = eng.launch_info(prec=32)
+                assert info['frames_per_wg'] % int(rpt) == 0, info
+                a = eng.decode(Y, 15, prec=32, sign_mode=1, want_soft=True)
+                assert np.array_equal(a['iters'], iters) and np.array_equal(a['hard'], hard), (m, n, rpt)
+                assert np.array_equal(a['converged'], conv) and np.array_equal(a['soft'], soft)
+                assert np.array_equal(a['ones'], hard.sum(1))
+            monkeypatch.delenv('LDPC_HIP_PACKED_RPT')

@@ -1,5 +1,10 @@
+#!/usr/bin/env python3
+"""Kernel time of the four 802.11n n = 1944 rates at the SNR each is quoted at (10^6 frames, early stop) and
+with every frame forced through all 50 iterations (10^5 hopeless frames): the second figure is the cost of an
+iteration, the difference to the first what a frame costs beyond its iterations.  LDPC_HIP_TEST_HOOKS=1 with
+LDPC_HIP_NO_PACKED=1 / LDPC_HIP_PACKED_RPT=2|4 selects the other short-code kernel / a group width."""
 import os, sys, time
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import ldpc_amd
 from ldpc_amd import codes
