@@ -64,10 +64,12 @@ int ldpc_device_count(void);
  * 161-181) and wifiMatrices.getWifiParityMatrix builds from its shift table
  * (wifiMatrices.py:12-34).
  * Replaces ldpcDecoder.__init__ (ldpc.py:225-247) and the dense device upload
- * of ldpcCUDA.py:538-564.  Limits: check degree <= 64, mb*roundup(Z,64) <= 1024,
- * nb <= 32*mb (LDPC_E_UNSUPPORTED beyond them: build the same matrix with
- * ldpc_create_csr).  A code whose frame state does not fit the 160 KB of LDS in
- * the arithmetic asked for is decoded from its edge list instead (slower, same results).
+ * of ldpcCUDA.py:538-564.  Limits: mb*roundup(Z,64) <= 1024, nb <= 32*mb
+ * (LDPC_E_UNSUPPORTED beyond them: build the same matrix with ldpc_create_csr).
+ * Any check degree: up to 128 edges per check (the state of a long gym episode,
+ * ldpc_env.py:293-317) the block-circulant kernels apply; beyond that, or when a
+ * frame's state does not fit the 160 KB of LDS in the arithmetic asked for, the code
+ * is decoded from its edge list instead (slower, same results).
  */
 int ldpc_create_qc(int device, int Z, int mb, int nb, const int32_t *blk_ptr,
                    const int32_t *shifts, ldpc_handle **out);
@@ -75,8 +77,9 @@ int ldpc_create_qc(int device, int Z, int mb, int nb, const int32_t *blk_ptr,
 /*
  * Build a decoder for an arbitrary sparse H given as CSR (row_ptr[m+1],
  * col_idx ascending inside a row).  Replaces ldpcDecoder.__init__
- * (ldpc.py:225-247) for matrices that are not block-circulant.
- * Limits: check degree <= 64.
+ * (ldpc.py:225-247) for matrices that are not block-circulant.  Any check
+ * degree (above 64 edges per check: one explicit message per edge in global
+ * memory, the slowest path).
  */
 int ldpc_create_csr(int device, int m, int n, const int32_t *row_ptr,
                     const int32_t *col_idx, ldpc_handle **out);

@@ -141,14 +141,20 @@ template <typename T> struct Vec2;
 template <> struct Vec2<float> { typedef float2 type; };
 template <> struct Vec2<double> { typedef double2 type; };
 
-template <bool S64> struct SignBits;
-template <> struct SignBits<false> {
+// One sign bit per edge of a check row, in a word of SB = 32, 64 or 128 bits (the widest: the state of a long gym
+// episode, where every action leaves a circulant of up to 7 hot bits, ldpc_env.py:293-317: 16 x 7 = 112 edges).
+template <int SB> struct SignBits;
+template <> struct SignBits<32> {
     typedef uint32_t type;
     struct __attribute__((aligned(8))) Meta { uint32_t signs; uint32_t idx; };
 };
-template <> struct SignBits<true> {
+template <> struct SignBits<64> {
     typedef uint64_t type;
     struct __attribute__((aligned(16))) Meta { uint64_t signs; uint32_t idx; uint32_t pad; };
+};
+template <> struct SignBits<128> {
+    typedef unsigned __int128 type;
+    struct __attribute__((aligned(16))) Meta { unsigned __int128 signs; uint32_t idx; uint32_t pad[3]; };
 };
 
 __device__ __forceinline__ float with_sign(float mag, uint32_t neg)
@@ -207,9 +213,13 @@ __device__ __forceinline__ double t_min(double a, double b) { return fmin(a, b);
 template <typename ST> __device__ __forceinline__ uint32_t parity_of(ST x);
 template <> __device__ __forceinline__ uint32_t parity_of<uint32_t>(uint32_t x) { return __popc(x) & 1u; }
 template <> __device__ __forceinline__ uint32_t parity_of<uint64_t>(uint64_t x) { return __popcll(x) & 1u; }
+template <> __device__ __forceinline__ uint32_t parity_of<unsigned __int128>(unsigned __int128 x)
+{
+    return (__popcll((uint64_t)x) + __popcll((uint64_t)(x >> 64))) & 1u;
+}
 
 // message a check row sends along its edge e, rebuilt from the row's compressed state
-template <typename T, bool S64>
+template <typename T, int S64>
 __device__ __forceinline__ T rebuild(const typename Vec2<T>::type mm,
                                      const typename SignBits<S64>::Meta mt, int e)
 {
@@ -230,7 +240,7 @@ __device__ __forceinline__ T rebuild(const typename Vec2<T>::type mm,
 // calcOutgoingValues (check pass) and checkNodesToVariableNodes + channel add
 // (variable pass); the syndrome of iteration k's posterior is evaluated by the
 // check pass of iteration k+1, whose other results are dropped if it is zero.
-template <typename T, bool S64, int CPT, int FPW>
+template <typename T, int S64, int CPT, int FPW>
 __global__ void __launch_bounds__(1024)
 #if QC_GENERIC_WAVES
 __attribute__((amdgpu_waves_per_eu(sizeof(T) == 4 && CPT <= 8 ? QC_GENERIC_WAVES : 4)))
@@ -510,7 +520,7 @@ __global__ void __launch_bounds__(256)
 csr_minsum_kernel(const CsrTables tb, const DecodeArgs a, unsigned char *workspace, size_t ws_stride)
 {
     typedef typename Vec2<T>::type T2;
-    typedef typename SignBits<true>::Meta Meta;
+    typedef typename SignBits<64>::Meta Meta;
     __shared__ int flags[2];
     __shared__ int ones_cnt;
     __shared__ int result[2];
@@ -572,7 +582,7 @@ csr_minsum_kernel(const CsrTables tb, const DecodeArgs a, unsigned char *workspa
                 uint64_t ns = 0;
                 for (int e = e0; e < e1; ++e) {
                     const int k = e - e0;
-                    const T v = post[tb.col_idx[e]] - rebuild<T, true>(om, ot, k);
+                    const T v = post[tb.col_idx[e]] - rebuild<T, 64>(om, ot, k);
                     ns |= (uint64_t)(v < T(0)) << k;
                     const T av = t_abs(v);
                     const bool lt = av < min1;
@@ -598,8 +608,119 @@ csr_minsum_kernel(const CsrTables tb, const DecodeArgs a, unsigned char *workspa
                 T acc = T(0);
                 for (int k = tb.col_ptr[c]; k < tb.col_ptr[c + 1]; ++k) {
                     const int r = tb.col_row[k];
-                    acc = acc + rebuild<T, true>(mins[r], meta[r], tb.col_e[k]);
+                    acc = acc + rebuild<T, 64>(mins[r], meta[r], tb.col_e[k]);
                 }
+                post[c] = acc + ych[c];
+            }
+            __syncthreads();
+        }
+        for (int qb = tid; qb < nbytes; qb += blockDim.x) {
+            uint32_t byte = 0;
+            for (int k = 0; k < 8; ++k)
+                if (qb * 8 + k < n) byte |= (uint32_t)(post[qb * 8 + k] > T(0)) << k;
+            if (a.hard) a.hard[frame * nbytes + qb] = (uint8_t)byte;
+            if (byte) atomicAdd(&ones_cnt, (int)__popc(byte));
+        }
+        if (a.soft) {
+            T *so = reinterpret_cast<T *>(a.soft) + frame * n;
+            for (int c = tid; c < n; c += blockDim.x) so[c] = post[c];
+        }
+        __syncthreads();
+        if (tid == 0) {
+            if (a.iters) a.iters[frame] = result[0];
+            if (a.conv) a.conv[frame] = (uint8_t)result[1];
+            if (a.ones) a.ones[frame] = ones_cnt;
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------- min-sum on an edge list, any check degree
+//
+// The state of a long gym episode: every action installs a circulant of up to 7 hot bits and the
+// environment keeps them all (ldpc_env.py:293-317), so check degrees grow past what the other kernels'
+// sign masks and unrolled rows hold (64).  One explicit message per edge in a per-workgroup slice of a
+// global workspace, rows and columns walked by loops: no degree enters a data structure.  Order of the
+// passes and arithmetic are csr_minsum_kernel's, so results are bit-identical; this is the slow, general
+// fallback.  Chained mode keeps the message array between frames.
+template <typename T>
+__global__ void __launch_bounds__(256)
+csr_wide_minsum_kernel(const CsrTables tb, const DecodeArgs a, unsigned char *workspace, size_t ws_stride)
+{
+    __shared__ int flags[2];
+    __shared__ int ones_cnt;
+    __shared__ int result[2];
+    const int m = tb.m, n = tb.n;
+    unsigned char *ws = workspace + (size_t)blockIdx.x * ws_stride;
+    T *post = reinterpret_cast<T *>(ws);
+    T *ych = post + n;
+    T *msg = ych + n;                                    // [E]: check-to-variable message of every edge (in a check pass: v)
+    const int tid = threadIdx.x;
+    const int nbytes = (n + 7) >> 3;
+    const T INF = t_inf(T(0));
+
+    for (int64_t frame = blockIdx.x; frame < a.n_frames; frame += gridDim.x) {
+        for (int c = tid; c < n; c += blockDim.x) {
+            const T yv = load_llr<T>(a.llr, a.llr_f64, frame * n + c) * T(a.llr_scale) + T(0);
+            ych[c] = yv;
+            post[c] = yv;
+        }
+        if (!a.chain)
+            for (int e = tid; e < tb.E; e += blockDim.x) msg[e] = T(0);      // fresh check nodes, ldpc.py:121
+        if (tid < 2) flags[tid] = 0;
+        if (tid == 0) ones_cnt = 0;
+        __syncthreads();
+        int it = 0;
+        for (;; ++it) {
+            const int par = it & 1;
+            // syndrome of the current posterior (isCodeword, ldpc.py:249-268)
+            bool bad_row = false;
+            for (int r = tid; r < m; r += blockDim.x) {
+                uint32_t sy = 0;
+                for (int e = tb.row_ptr[r]; e < tb.row_ptr[r + 1]; ++e)
+                    sy ^= (uint32_t)(post[tb.col_idx[e]] > T(0));
+                bad_row |= (sy != 0);
+            }
+            if (bad_row) flags[par] = 1;
+            __syncthreads();
+            const int bad = flags[par];
+            if (bad == 0 || it >= a.max_iters) {                             // ldpc.py:332-335
+                if (tid == 0) { result[0] = it; result[1] = (bad == 0); }
+                break;
+            }
+            if (tid == 0) flags[par ^ 1] = 0;
+            // check pass (ldpc.py:150-163, 174-202)
+            for (int r = tid; r < m; r += blockDim.x) {
+                const int e0 = tb.row_ptr[r], e1 = tb.row_ptr[r + 1];
+                T min1 = INF, min2 = INF;
+                int idx = e0;
+                uint32_t neg = 0;
+                for (int e = e0; e < e1; ++e) {
+                    const T v = post[tb.col_idx[e]] - msg[e];
+                    msg[e] = v;
+                    neg ^= (uint32_t)(v < T(0));                             // sign(0) = +1, ldpc.py:139
+                    const T av = t_abs(v);
+                    const bool lt = av < min1;
+                    min2 = t_mid(min1, min2, av);
+                    idx = lt ? e : idx;
+                    min1 = t_min(min1, av);
+                }
+                uint32_t S = neg;
+                if (a.sign_mode == LDPC_SIGN_CORRECTED) S ^= (uint32_t)(e1 - e0) & 1u;
+                min1 = ms_correct(min1, a.ms_alpha, a.ms_beta);
+                min2 = ms_correct(min2, a.ms_alpha, a.ms_beta);
+                for (int e = e0; e < e1; ++e) {
+                    const T mag = e == idx ? min2 : min1;                    // ldpc.py:190-191
+                    const uint32_t ng = (uint32_t)(msg[e] < T(0)) ^ S;
+                    msg[e] = ng ? -mag : mag;
+                }
+            }
+            __syncthreads();
+            // variable pass: ordered sum over ascending check index, channel last (ldpc.py:298-303, 322)
+            for (int c = tid; c < n; c += blockDim.x) {
+                T acc = T(0);
+                for (int k = tb.col_ptr[c]; k < tb.col_ptr[c + 1]; ++k)
+                    acc = acc + msg[tb.row_ptr[tb.col_row[k]] + tb.col_e[k]];
                 post[c] = acc + ych[c];
             }
             __syncthreads();
@@ -671,15 +792,15 @@ csr_spa_kernel(const CsrTables tb, const DecodeArgs a, unsigned char *workspace,
             bool bad_row = false;
             for (int r = tid; r < m; r += blockDim.x) {
                 const int e0 = tb.row_ptr[r], e1 = tb.row_ptr[r + 1];
-                uint64_t ns = 0;
-                uint32_t sy = 0;
+                uint32_t sy = 0, neg = 0;
                 T F1 = T(-1), rest = T(0);
                 int arg = -1;
                 for (int e = e0; e < e1; ++e) {
                     const T p = post[tb.col_idx[e]];
                     sy ^= (uint32_t)(p > T(0));                      // slicer, ldpc.py:47
                     const T v = p - msg[e];                          // receive, ldpc.py:161
-                    ns |= (uint64_t)(v < T(0)) << (e - e0);          // sign(0) = +1, ldpc.py:139
+                    const bool ng = v < T(0);                        // sign(0) = +1, ldpc.py:139
+                    neg ^= (uint32_t)ng;
                     const T F = spa_phi(spa_clamp(t_abs(v)));
                     if (F > F1) {
                         if (arg >= 0) rest = rest + F1;
@@ -688,17 +809,18 @@ csr_spa_kernel(const CsrTables tb, const DecodeArgs a, unsigned char *workspace,
                     } else {
                         rest = rest + F;
                     }
-                    msg[e] = F;
+                    msg[e] = ng ? -F : F;                            // F > 0 (the clamp): its sign carries the edge's (any degree)
                 }
                 bad_row |= (sy != 0);
                 const int deg = e1 - e0;
-                uint32_t S = parity_of<uint64_t>(ns);
+                uint32_t S = neg;
                 if (a.sign_mode == LDPC_SIGN_CORRECTED) S ^= (uint32_t)deg & 1u;
                 for (int e = e0; e < e1; ++e) {
-                    const T x = (e == arg) ? rest : (rest - msg[e]) + F1;
+                    const T sf = msg[e];
+                    const T x = (e == arg) ? rest : (rest - t_abs(sf)) + F1;
                     const T mag = spa_phi(spa_clamp(x));
-                    const uint32_t neg = (uint32_t)((ns >> (e - e0)) & 1u) ^ S;
-                    msg[e] = neg ? -mag : mag;
+                    const uint32_t ng = (uint32_t)(sf < T(0)) ^ S;
+                    msg[e] = ng ? -mag : mag;
                 }
             }
             if (bad_row) flags[par] = 1;
@@ -985,6 +1107,7 @@ struct ldpc_handle {
     hipStream_t stream = nullptr;
     bool is_qc = false;
     int m = 0, n = 0, E = 0, max_row_deg = 0;
+    bool wide = false;        // some check has more than 64 edges: of the edge-list min-sum kernels the any-degree one applies
     // QC
     QcTables qc{};
     int cols_per_thread = 0;
@@ -1314,7 +1437,7 @@ extern "C" int ldpc_create_qc(int device, int Z, int mb, int nb, const int32_t *
         row_ptr[b + 1] = (int)row_ent.size();
         max_deg = std::max(max_deg, cnt);
     }
-    if (max_deg > 64) return fail(LDPC_E_UNSUPPORTED, "check degree %d exceeds 64", max_deg);
+    const bool wide = max_deg > 128;     // beyond the block-circulant kernels' rows (128 sign bits): decoded from the edge list only
     for (int j = 0; j < nb; ++j) {
         for (int b = 0; b < mb; ++b) {
             const int k0 = blk_ptr[b * nb + j], k1 = blk_ptr[b * nb + j + 1];
@@ -1332,11 +1455,20 @@ extern "C" int ldpc_create_qc(int device, int Z, int mb, int nb, const int32_t *
     if (!h) return fail(LDPC_E_NOMEM, "out of host memory");
     int rc = open_device(device, h);
     if (rc) { delete h; return rc; }
-    h->is_qc = true;
+    h->is_qc = !wide;
+    h->wide = max_deg > 64;
     h->m = mb * Z; h->n = nb * Z; h->E = blk_ptr[nblk] * Z; h->max_row_deg = max_deg;
     h->cols_per_thread = (nb + mb - 1) / mb;
     h->qc.Z = Z; h->qc.Zp = Zp; h->qc.mb = mb; h->qc.nb = nb; h->qc.m = h->m; h->qc.n = h->n;
     h->qc.n_ent = (int)row_ent.size(); h->qc.n_grp = (int)col_grp.size();
+    if (wide) {
+        if ((rc = stage_qc_edges(h, blk_ptr, shifts)) || (rc = commit_tables(h, &h->arena, &h->arena_cap))) {
+            ldpc_destroy(h);
+            return rc;
+        }
+        *out = h;
+        return 0;
+    }
     // regular structure?  (same weight W in {1,2} for every non-empty block, and a block
     // geometry one of the unrolled instantiations covers)
     {
@@ -1471,7 +1603,6 @@ extern "C" int ldpc_create_csr(int device, int m, int n, const int32_t *row_ptr,
     }
     const int E = row_ptr[m];
     if (E > 0 && !col_idx) return fail(LDPC_E_ARG, "col_idx is NULL");
-    if (max_deg > 64) return fail(LDPC_E_UNSUPPORTED, "check degree %d exceeds 64", max_deg);
     for (int r = 0; r < m; ++r)
         for (int e = row_ptr[r]; e < row_ptr[r + 1]; ++e) {
             if (col_idx[e] < 0 || col_idx[e] >= n) return fail(LDPC_E_ARG, "column index out of range");
@@ -1484,6 +1615,7 @@ extern "C" int ldpc_create_csr(int device, int m, int n, const int32_t *row_ptr,
     int rc = open_device(device, h);
     if (rc) { delete h; return rc; }
     h->is_qc = false;
+    h->wide = max_deg > 64;
     h->m = m; h->n = n; h->E = E; h->max_row_deg = max_deg;
     if ((rc = build_csr(h, rp, ci, m, n)) || (rc = commit_tables(h, &h->arena, &h->arena_cap))) {
         ldpc_destroy(h);
@@ -1542,7 +1674,7 @@ extern "C" int ldpc_sync(ldpc_handle *h)
 }
 
 // ---------------------------------------------------------------- kernel selection
-template <typename T, bool S64, int CPT, int FPW>
+template <typename T, int S64, int CPT, int FPW>
 static size_t qc_lds_bytes(const QcTables &tb)
 {
     const size_t slots = (size_t)FPW * tb.mb * tb.Zp;
@@ -1555,7 +1687,7 @@ static size_t qc_lds_bytes(const QcTables &tb)
     return (b + 15) & ~(size_t)15;
 }
 
-template <typename T, bool S64, int CPT, int FPW>
+template <typename T, int S64, int CPT, int FPW>
 static int qc_pick(const ldpc_handle *h, Launch *L)
 {
     L->fn = reinterpret_cast<const void *>(&qc_minsum_kernel<T, S64, CPT, FPW>);
@@ -1565,7 +1697,7 @@ static int qc_pick(const ldpc_handle *h, Launch *L)
     return 0;
 }
 
-template <typename T, bool S64>
+template <typename T, int S64>
 static int qc_select(const ldpc_handle *h, bool chained, Launch *L)
 {
     const int cpt = h->cols_per_thread;
@@ -1639,6 +1771,7 @@ static int reg_select(const ldpc_handle *h, bool chained, Launch *L)
 static size_t csr_ws_stride(const ldpc_handle *h, int prec)
 {
     const size_t ts = prec == 64 ? 8 : 4;
+    if (h->wide) return ((((size_t)2 * h->n + (size_t)h->E) * ts) + 255) & ~(size_t)255;     // posteriors, channel values, one message per edge
     size_t b = (((size_t)2 * h->n * ts) + 15) & ~(size_t)15;
     b += (size_t)h->m * 2 * ts;
     b += (size_t)h->m * 16;
@@ -1837,12 +1970,12 @@ static int select_kernel(ldpc_handle *h, int algo, int prec, bool chained, Launc
         return 0;
     }
     if (h->is_qc) {
-        const bool s64 = h->max_row_deg > 32;
+        const int sb = h->max_row_deg > 64 ? 128 : h->max_row_deg > 32 ? 64 : 32;
         int rc;
         if (planes_applies(h, prec, chained)) rc = planes_pick(h, false, L);
         else if (h->is_regular) rc = prec == 32 ? reg_select<float>(h, chained, L) : reg_select<double>(h, chained, L);
-        else if (prec == 32) rc = s64 ? qc_select<float, true>(h, chained, L) : qc_select<float, false>(h, chained, L);
-        else            rc = s64 ? qc_select<double, true>(h, chained, L) : qc_select<double, false>(h, chained, L);
+        else if (prec == 32) rc = sb == 128 ? qc_select<float, 128>(h, chained, L) : sb == 64 ? qc_select<float, 64>(h, chained, L) : qc_select<float, 32>(h, chained, L);
+        else            rc = sb == 128 ? qc_select<double, 128>(h, chained, L) : sb == 64 ? qc_select<double, 64>(h, chained, L) : qc_select<double, 32>(h, chained, L);
         if (rc) return rc;
         if (L->lds <= h->lds_max) {
             if ((rc = blocks_per_cu(h->device, L->fn, L->block, L->lds, &per_cu, L->planes))) return rc;
@@ -1854,8 +1987,12 @@ static int select_kernel(ldpc_handle *h, int algo, int prec, bool chained, Launc
         // with the state in a global workspace (every QC handle carries its edge list too)
         *L = Launch();
     }
-    L->fn = prec == 32 ? reinterpret_cast<const void *>(&csr_minsum_kernel<float>)
-                       : reinterpret_cast<const void *>(&csr_minsum_kernel<double>);
+    if (h->wide)
+        L->fn = prec == 32 ? reinterpret_cast<const void *>(&csr_wide_minsum_kernel<float>)
+                           : reinterpret_cast<const void *>(&csr_wide_minsum_kernel<double>);
+    else
+        L->fn = prec == 32 ? reinterpret_cast<const void *>(&csr_minsum_kernel<float>)
+                           : reinterpret_cast<const void *>(&csr_minsum_kernel<double>);
     L->csr = true;
     L->block = 256;
     L->fpw = 1;
@@ -1887,10 +2024,10 @@ static int select_launch(ldpc_handle *h, int algo, int prec, int64_t n_frames, b
 // Bytes of persistent check-node state of a chained decoder.
 static size_t chain_bytes(const ldpc_handle *h, int prec)
 {
-    // edge-list kernel: its whole workspace slice persists; QC kernels: 32 bytes per row slot
+    // edge-list kernel: its whole workspace slice persists; QC kernels: 48 bytes per row slot
     // cover the state layout of either of them.  A QC code whose frame state does not fit the
     // LDS runs on the edge-list kernel, so the buffer is sized for whichever is larger.
-    const size_t qc = h->is_qc ? (size_t)h->qc.mb * h->qc.Zp * 32 : 0;
+    const size_t qc = h->is_qc ? (size_t)h->qc.mb * h->qc.Zp * 48 : 0;
     return std::max(qc, csr_ws_stride(h, prec));
 }
 

@@ -84,6 +84,18 @@ def mutation_rows(kind):
         prng.choice(511, 3, replace=False)
         return [(1, 9, sorted(prng.choice(511, 7, replace=False).tolist())),
                 (0, 12, sorted(prng.choice(511, 1, replace=False).tolist()))]
+    if kind == 'many':
+        # the state after a long episode: 24 actions, each a circulant of 1...7 hot bits somewhere (the
+        # environment keeps what earlier actions installed, ldpc_env.py:293-317); check degrees reach 70 and more
+        prng = np.random.RandomState(20211227)
+        rows = []
+        for _ in range(24):
+            b, j, w = int(prng.randint(2)), int(prng.randint(16)), int(prng.randint(1, 8))
+            rows.append((b, j, sorted(prng.choice(511, w, replace=False).tolist())))
+        for j in range(0, 16, 2):                      # and a block-row filled with heavy circulants
+            rows.append((0, j, sorted(prng.choice(511, 7, replace=False).tolist())))
+        rows.append((1, 5, sorted(prng.choice(511, 5, replace=False).tolist())))
+        return rows
     raise ValueError(kind)
 
 
@@ -214,10 +226,12 @@ def main():
     ap.add_argument('--quick', action='store_true', help='2 frames per point (plumbing check)')
     ap.add_argument('--jobs', type=int, default=8)
     ap.add_argument('--only-chained', action='store_true', help='only (re)generate chained_decoder.npz')
+    ap.add_argument('--only', default=None, help='only (re)generate the file of this code, e.g. nearEarth_mut_many')
     args = ap.parse_args()
     nf = 2 if args.quick else None
     os.makedirs(OUT, exist_ok=True)
-    gen_chained()
+    if not args.only:
+        gen_chained()
     if args.only_chained:
         return
 
@@ -236,6 +250,12 @@ def main():
     plan.append(('nearEarth_mut_w3', 6003, 6.0, nf or 8, None))
     plan.append(('nearEarth_mut_w7', 6002, 3.4, nf or 8, None))
     plan.append(('nearEarth_mut_w7', 6004, 6.0, nf or 8, None))
+    # check degrees above 64 (the state of a long gym episode)
+    plan.append(('nearEarth_mut_many', 6100, 3.0, nf or 6, None))
+    plan.append(('nearEarth_mut_many', 6103, 4.0, nf or 6, None))
+    plan.append(('nearEarth_mut_many', 6101, 5.0, nf or 4, None))
+    plan.append(('nearEarth_mut_many', 6102, 8.0, nf or 6, None))
+    plan.append(('nearEarth_mut_many', 1, 0.0, 1, 'flip0'))
     plan.append(('wifi_5_6', 7001, 4.0, nf or 32, None))
     plan.append(('wifi_5_6', 7003, 6.0, nf or 32, None))
     plan.append(('wifi_5_6', 7002, 8.0, nf or 32, None))
@@ -244,6 +264,8 @@ def main():
     plan.append(('rand_24_48', 8003, 4.0, nf or 64, None))
     plan.append(('rand_24_48', 8002, 6.0, nf or 32, None))
 
+    if args.only:
+        plan = [j for j in plan if j[0] == args.only]
     # split long jobs so the pool stays busy: one job per (point, chunk of frames)
     # is not possible (one RandomState stream per point), so just sort by cost.
     plan.sort(key=lambda j: -(j[3] * (60 - 10 * min(j[2], 5.0))))
@@ -286,6 +308,8 @@ def main():
                   f"({r['seconds']:.0f} s)")
         np.savez_compressed(os.path.join(OUT, name + '.npz'), **arrays)
 
+    if args.only:
+        return
     # berStatistics rows of the reference's evaluateCodeAtSingleTransmission (ldpc.py:391-430)
     # on a freshly loaded module (module-global PRNG at its initial state, ldpc.py:24).
     import fileHandler

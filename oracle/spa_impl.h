@@ -47,12 +47,12 @@ static void FN(spa_frame)(const oracle_graph *g, int sign_mode, int max_iters, R
         ++it;
         for (int r = 0; r < m; ++r) {
             const int e0 = rp[r], e1 = rp[r + 1];
-            uint64_t ns = 0;
             REAL F1 = (REAL)-1, rest = (REAL)0;
             int arg = -1, neg = 0;
             for (int e = e0; e < e1; ++e) {
                 const REAL v = post[ci[e]] - c2v[e];
-                if (v < (REAL)0) { ns |= (uint64_t)1 << (e - e0); neg ^= 1; }
+                const int minus_v = v < (REAL)0;                 /* sign(0) = +1 */
+                neg ^= minus_v;
                 const REAL F = PHI(FN(spa_clamp)(FABS(v)));
                 if (F > F1) {
                     if (arg >= 0) rest = rest + F1;
@@ -61,13 +61,14 @@ static void FN(spa_frame)(const oracle_graph *g, int sign_mode, int max_iters, R
                 } else {
                     rest = rest + F;
                 }
-                c2v[e] = F;
+                c2v[e] = minus_v ? -F : F;                       /* F > 0 (the clamp): its sign carries the edge's, for any degree */
             }
             if (sign_mode == 1 && ((e1 - e0) & 1)) neg ^= 1;
             for (int e = e0; e < e1; ++e) {
-                const REAL x = (e == arg) ? rest : (rest - c2v[e]) + F1;
+                const REAL sf = c2v[e];
+                const REAL x = (e == arg) ? rest : (rest - FABS(sf)) + F1;
                 const REAL mag = PHI(FN(spa_clamp)(x));
-                const int minus = (int)((ns >> (e - e0)) & 1) ^ neg;
+                const int minus = (sf < (REAL)0) ^ neg;
                 c2v[e] = minus ? -mag : mag;
             }
         }

@@ -27,6 +27,18 @@ def mutation_rows(kind):
         prng.choice(511, 3, replace=False)
         return [(1, 9, sorted(prng.choice(511, 7, replace=False).tolist())),
                 (0, 12, sorted(prng.choice(511, 1, replace=False).tolist()))]
+    if kind == 'many':
+        # the state after a long episode: 24 actions, each a circulant of 1...7 hot bits somewhere (the
+        # environment keeps what earlier actions installed, ldpc_env.py:293-317); check degrees reach 70 and more
+        prng = np.random.RandomState(20211227)
+        rows = []
+        for _ in range(24):
+            b, j, w = int(prng.randint(2)), int(prng.randint(16)), int(prng.randint(1, 8))
+            rows.append((b, j, sorted(prng.choice(511, w, replace=False).tolist())))
+        for j in range(0, 16, 2):                      # and a block-row filled with heavy circulants
+            rows.append((0, j, sorted(prng.choice(511, 7, replace=False).tolist())))
+        rows.append((1, 5, sorted(prng.choice(511, 5, replace=False).tolist())))
+        return rows
     raise ValueError(kind)
 
 
@@ -86,7 +98,7 @@ def golden_points(name):
 
 
 ALL_CODES = ['nearEarth', 'nearEarth_zero_0_0', 'nearEarth_zero_0_7', 'nearEarth_zero_1_3',
-             'nearEarth_zero_1_15', 'nearEarth_mut_w3', 'nearEarth_mut_w7', 'wifi_5_6', 'rand_24_48']
+             'nearEarth_zero_1_15', 'nearEarth_mut_w3', 'nearEarth_mut_w7', 'nearEarth_mut_many', 'wifi_5_6', 'rand_24_48']
 
 
 @pytest.fixture(scope='session')

@@ -82,7 +82,7 @@ def test_f32_bit_exact_against_oracle(engines, oracle_mod, name):
         assert np.array_equal(r['soft'], soft)
 
 
-@pytest.mark.parametrize('name', ['nearEarth_mut_w3', 'nearEarth_mut_w7', 'wifi_5_6', 'rand_24_48'])
+@pytest.mark.parametrize('name', ['nearEarth_mut_w3', 'nearEarth_mut_w7', 'nearEarth_mut_many', 'wifi_5_6', 'rand_24_48'])
 def test_corrected_sign_mode_against_oracle(engines, oracle_mod, name):
     """Odd check degrees: opt-in sign rule (-1)^degree, both arithmetic widths."""
     eng = engines(name)
@@ -107,7 +107,7 @@ def test_chained_decoder_against_oracle(engines, oracle_mod, prec):
     """ldpc_decode_chained: state carried across frames AND across calls; reset works."""
     import ldpc_amd
     dt = np.float64 if prec == 64 else np.float32
-    for name in ('nearEarth', 'nearEarth_mut_w7', 'wifi_5_6', 'rand_24_48'):
+    for name in ('nearEarth', 'nearEarth_mut_w7', 'nearEarth_mut_many', 'wifi_5_6', 'rand_24_48'):
         qc, H = build_code(name)
         orc = oracle_mod.Oracle(H)
         pts = [p for p in golden_points(name) if not p['special']]
@@ -622,6 +622,73 @@ def test_edge_tables_are_built_on_first_need(oracle_mod, monkeypatch):
         assert np.array_equal(x['hard'], y['hard']) and np.array_equal(x['iters'], y['iters']) and np.array_equal(x['converged'], y['converged'])
     assert np.array_equal(outs[1][0]['hard'], outs[1][2]['hard'])
     assert outs[1][1]['iters'].max() > 1
+
+
+def test_check_degrees_above_64(oracle_mod):
+    """The state of a long gym episode (every action leaves a circulant of up to 7 hot bits, ldpc_env.py:293-317)
+    has checks of 84 and 55 edges.  Such a code decodes from the edge list with one explicit message per
+    edge, whatever the degree: float64 against the reference's own results is in the golden tests; here both
+    sign rules and precisions against the oracle, sum-product, the dense-matrix and CSR routes, the sweep
+    driver, and an unstructured matrix with a check of 100 edges."""
+    import ldpc_amd
+    qc, H = build_code('nearEarth_mut_many')
+    assert max(qc.row_degrees()) == 84
+    orc = oracle_mod.Oracle(H)
+    Y = make_llrs(31, 6.0, qc.n, 12)
+    Y[3] = np.float32(-1.0)
+    Y[5, :40] = 0.0
+    with ldpc_amd.Decoder(qc) as eng, ldpc_amd.Decoder(H) as dense_eng:
+        for e in (eng, dense_eng):                        # up to 128 edges per check: the table-driven kernel, state in LDS
+            assert e.launch_info(prec=32)['block'] == 1024 and e.launch_info(prec=64)['lds_bytes'] > 8 * qc.n
+        for prec, dt in ((32, np.float32), (64, np.float64)):
+            for sm in (1, 0):
+                hard, iters, conv, soft = orc.minsum(Y.astype(dt), 30, prec=prec, sign_mode=sm, threads=8)
+                for e in (eng, dense_eng):
+                    r = e.decode(Y, 30, prec=prec, sign_mode=sm, want_soft=True)
+                    assert np.array_equal(r['iters'], iters) and np.array_equal(r['converged'], conv), (prec, sm)
+                    assert np.array_equal(r['hard'], hard) and np.array_equal(r['soft'], soft)
+                if sm == 1:
+                    assert conv.sum() >= 8 and hard[conv == 1].sum() == 0
+            hs, is_, cs, _ = orc.spa(Y.astype(dt), 8.0, 30, prec=prec, sign_mode=1, want_soft=False, threads=8)
+            r = eng.decode((Y * np.float32(8.0)).astype(dt), 30, prec=prec, algo=ldpc_amd.ALGO_SUMPRODUCT, sign_mode=1)
+            cv = cs == 1
+            assert cv.sum() >= 8
+            assert np.array_equal(r['iters'][cv], is_[cv]) and np.array_equal(r['hard'][cv], hs[cv])
+        # re-used decoder (check-node messages carried from frame to frame)
+        st = orc.new_state(32)
+        hard, iters, conv, _ = orc.minsum(Y, 30, prec=32, sign_mode=1, want_soft=False, state=st)
+        r = eng.decode(Y, 30, prec=32, sign_mode=1, chained=True)
+        assert np.array_equal(r['iters'], iters) and np.array_equal(r['hard'], hard)
+        cnt, pf = eng.eval_awgn([5.0, 7.0], 300, seed=3, sign_mode=1, per_frame=True)
+        assert (cnt[:, 0] == 300).all() and cnt[1, 1] <= cnt[0, 1] and pf.shape == (2, 300, 4)
+    # beyond 128 edges per check: block-circulant or not, from the edge list with one message per edge
+    prng = np.random.RandomState(6)
+    big = qc
+    for j in range(16):
+        big = big.with_block(0, j, sorted(prng.choice(511, 9 if j < 4 else 8, replace=False).tolist()))
+    assert max(big.row_degrees()) == 132
+    orc = oracle_mod.Oracle(big.to_dense())
+    Y = make_llrs(32, 7.0, big.n, 6)
+    with ldpc_amd.Decoder(big) as eng:
+        assert eng.launch_info(prec=32)['block'] == 256 and eng.launch_info(prec=32)['lds_bytes'] == 0
+        for prec, dt in ((32, np.float32), (64, np.float64)):
+            hard, iters, conv, soft = orc.minsum(Y.astype(dt), 12, prec=prec, sign_mode=1, threads=8)
+            r = eng.decode(Y, 12, prec=prec, sign_mode=1, want_soft=True)
+            assert np.array_equal(r['iters'], iters) and np.array_equal(r['hard'], hard) and np.array_equal(r['soft'], soft)
+    prng = np.random.RandomState(5)
+    m, n = 60, 240
+    Hr = np.zeros((m, n), np.int32)
+    for c in range(n):
+        Hr[prng.choice(m, 3, replace=False), c] = 1
+    Hr[7, prng.choice(n, 100, replace=False)] = 1
+    assert Hr.sum(1).max() >= 100
+    orc = oracle_mod.Oracle(Hr)
+    Y = make_llrs(9, 4.0, n, 33)
+    with ldpc_amd.Decoder(Hr) as eng:
+        for prec, dt in ((32, np.float32), (64, np.float64)):
+            hard, iters, conv, soft = orc.minsum(Y.astype(dt), 25, prec=prec, sign_mode=1, threads=4)
+            r = eng.decode(Y, 25, prec=prec, sign_mode=1, want_soft=True)
+            assert np.array_equal(r['iters'], iters) and np.array_equal(r['hard'], hard) and np.array_equal(r['soft'], soft)
 
 
 def test_heavy_circulants_on_the_message_plane_kernel(oracle_mod, monkeypatch):
