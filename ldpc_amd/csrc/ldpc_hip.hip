@@ -165,6 +165,17 @@ __device__ __forceinline__ double with_sign(double mag, uint32_t neg)
 {
     return __hiloint2double(__double2hiint(mag) | (int)(neg << 31), __double2loint(mag));
 }
+// the same with the sign already in bit 31
+__device__ __forceinline__ float with_sign_bit(float mag, uint32_t bit31)
+{
+    return __uint_as_float(__float_as_uint(mag) | bit31);
+}
+__device__ __forceinline__ double with_sign_bit(double mag, uint32_t bit31)
+{
+    return __hiloint2double(__double2hiint(mag) | (int)bit31, __double2loint(mag));
+}
+__device__ __forceinline__ uint32_t sign_word(float v) { return __float_as_uint(v); }
+__device__ __forceinline__ uint32_t sign_word(double v) { return (uint32_t)__double2hiint(v); }
 // channel value (frame-major) as the arithmetic type T
 template <typename T>
 __device__ __forceinline__ T load_llr(const void *llr, int is_f64, int64_t idx)
@@ -227,6 +238,31 @@ __device__ __forceinline__ T rebuild(const typename Vec2<T>::type mm,
     return with_sign(mag, (uint32_t)((mt.signs >> e) & 1u));
 }
 
+// Compressed state of a check row in the table-driven kernel below: { min1, min2 } and, next to it, NW = SB / 32
+// words of sign bits (bit 31 - k of word w: the message on edge 32 w + k is negative; first edge highest, so that a
+// shift by k puts an edge's bit where a float keeps its sign) followed by the arg-min edge.
+// The variable pass reads, per edge, the one sign word that holds its bit, the arg-min and the two magnitudes:
+// 16 bytes, whatever the row's degree.  MW = NW + 1 words per row: odd for SB = 64 and 128, so that the rows
+// neighbouring lanes read lie on different LDS banks (SB = 32: the two words are read as one 8-byte value).
+template <int SB> struct RowMeta { enum { NW = SB / 32, MW = NW + 1 }; };
+
+template <typename T, int SB>
+__device__ __forceinline__ T rebuild_row(const typename Vec2<T>::type *mins, const uint32_t *meta, int slot, int e)
+{
+    enum { NW = RowMeta<SB>::NW, MW = RowMeta<SB>::MW };
+    uint32_t word, idx;
+    if (SB == 32) {
+        const uint2 wi = *reinterpret_cast<const uint2 *>(meta + (size_t)slot * MW);
+        word = wi.x; idx = wi.y;
+    } else {
+        word = meta[slot * MW + (e >> 5)];
+        idx = meta[slot * MW + NW];
+    }
+    const typename Vec2<T>::type mm = mins[slot];
+    const T mag = (idx == (uint32_t)e) ? mm.y : mm.x;
+    return with_sign_bit(mag, (word << (e & 31)) & 0x80000000u);
+}
+
 // ---------------------------------------------------------------- QC min-sum kernel
 //
 // Thread layout: blockDim = FPW * mb * Zp, Zp = roundup(Z, 64).  Thread
@@ -248,8 +284,7 @@ __attribute__((amdgpu_waves_per_eu(sizeof(T) == 4 && CPT <= 8 ? QC_GENERIC_WAVES
 qc_minsum_kernel(const QcTables tb, const DecodeArgs a)
 {
     typedef typename Vec2<T>::type T2;
-    typedef typename SignBits<S64>::type ST;
-    typedef typename SignBits<S64>::Meta Meta;
+    enum { NW = RowMeta<S64>::NW, MW = RowMeta<S64>::MW };
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int Z = tb.Z, Zp = tb.Zp, mb = tb.mb, nb = tb.nb, n = tb.n;
@@ -260,8 +295,8 @@ qc_minsum_kernel(const QcTables tb, const DecodeArgs a)
     off += (((size_t)FPW * n * sizeof(T)) + 15) & ~(size_t)15;
     T2 *mins = reinterpret_cast<T2 *>(smem + off);
     off += (size_t)slots * sizeof(T2);
-    Meta *meta = reinterpret_cast<Meta *>(smem + off);
-    off += (size_t)slots * sizeof(Meta);
+    uint32_t *meta = reinterpret_cast<uint32_t *>(smem + off);     // [slots][MW]: sign words, arg-min
+    off += ((size_t)slots * MW * 4 + 15) & ~(size_t)15;
     int *flags = reinterpret_cast<int *>(smem + off);   // [2][FPW] "syndrome non-zero"
     int *ones_cnt = flags + 2 * FPW;                    // [FPW]
     off = (off + 3 * FPW * sizeof(int) + 15) & ~(size_t)15;
@@ -293,14 +328,18 @@ qc_minsum_kernel(const QcTables tb, const DecodeArgs a)
 
     // outgoing messages of this thread's check row, compressed
     T omin1 = T(0), omin2 = T(0);
-    ST osigns = 0;
+    uint32_t osw[NW];
     uint32_t oidx = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) osw[w] = 0;
     T2 *chain_mins = reinterpret_cast<T2 *>(a.chain);
-    Meta *chain_meta = reinterpret_cast<Meta *>(a.chain + (size_t)slots * sizeof(T2));
+    uint32_t *chain_meta = reinterpret_cast<uint32_t *>(a.chain + (size_t)slots * sizeof(T2));
     if (a.chain && live) {
         const T2 mm = chain_mins[slot];
-        const Meta mt = chain_meta[slot];
-        omin1 = mm.x; omin2 = mm.y; osigns = mt.signs; oidx = mt.idx;
+        omin1 = mm.x; omin2 = mm.y;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) osw[w] = chain_meta[slot * MW + w];
+        oidx = chain_meta[slot * MW + NW];
     }
 
     const int64_t n_fblocks = (a.n_frames + FPW - 1) / FPW;
@@ -344,7 +383,9 @@ qc_minsum_kernel(const QcTables tb, const DecodeArgs a)
             // fresh check nodes: every outgoing message is +0 (checkNode.__init__, ldpc.py:121).
             // A chained decoder keeps them instead: decoderSet resets only the variable
             // nodes (ldpc.py:270-274).
-            omin1 = T(0); omin2 = T(0); osigns = 0; oidx = 0;
+            omin1 = T(0); omin2 = T(0); oidx = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) osw[w] = 0;
         }
         uint32_t act_mask = 0;       // frame slots still iterating (same value in every thread)
 #pragma unroll
@@ -360,38 +401,59 @@ qc_minsum_kernel(const QcTables tb, const DecodeArgs a)
             // ================= check pass (+ syndrome of the current posterior)
             T min1 = INF, min2 = INF;
             uint32_t idx = 0;
-            ST ns = 0;
+            uint32_t nsw[NW];
+#pragma unroll
+            for (int w = 0; w < NW; ++w) nsw[w] = 0;
             if (active && live) {
                 unsigned long long synd = 0;
+                uint32_t S = 0;
+                // 32 edges per sign word; the word number is a constant in each copy of the loop
+#pragma unroll
+                for (int w = 0; w < NW; ++w) {
+                    const int lim = deg - 32 * w < 32 ? deg - 32 * w : 32;       // uniform
+                    if (lim > 0) {
+                        const uint32_t ow = osw[w];
+                        uint32_t nw = 0;
 #pragma unroll 4
-                for (int e = 0; e < deg; ++e) {
-                    const int2 ent = l_row_ent[re0 + e];
-                    uint32_t c = (uint32_t)(i + ent.y);
-                    c = min(c, c - (uint32_t)Z);                 // (i + s) mod Z
-                    const T p = post[fbase + ent.x + (int)c];
-                    synd ^= __ballot(p > T(0));                  // slicer, ldpc.py:47
-                    const T mag_old = (oidx == (uint32_t)e) ? omin2 : omin1;
-                    const T c_old = with_sign(mag_old, (uint32_t)((osigns >> e) & 1u));
-                    const T v = p - c_old;                       // receive, ldpc.py:161
-                    const uint32_t neg = v < T(0);               // setSign, ldpc.py:139
-                    ns |= (ST)neg << e;
-                    const T av = t_abs(v);                       // ldpc.py:178
-                    const bool lt = av < min1;
-                    min2 = t_mid(min1, min2, av);
-                    idx = lt ? (uint32_t)e : idx;
-                    min1 = t_min(min1, av);
+                        for (int k = 0; k < lim; ++k) {
+                            const int e = 32 * w + k;
+                            const int2 ent = l_row_ent[re0 + e];
+                            uint32_t c = (uint32_t)(i + ent.y);
+                            c = min(c, c - (uint32_t)Z);                 // (i + s) mod Z
+                            const T p = post[fbase + ent.x + (int)c];
+                            synd ^= __ballot(p > T(0));                  // slicer, ldpc.py:47
+                            const T mag_old = (oidx == (uint32_t)e) ? omin2 : omin1;
+                            const T c_old = with_sign_bit(mag_old, (ow << k) & 0x80000000u);
+                            const T v = p - c_old;                       // receive, ldpc.py:161
+                            // setSign, ldpc.py:139: v is never -0 (x - x is +0, and no posterior is -0), so its sign
+                            // bit says "negative"; collected first edge highest
+                            nw = __builtin_amdgcn_alignbit(nw, sign_word(v), 31);
+                            const T av = t_abs(v);                       // ldpc.py:178
+                            const bool lt = av < min1;
+                            min2 = t_mid(min1, min2, av);
+                            idx = lt ? (uint32_t)e : idx;
+                            min1 = t_min(min1, av);
+                        }
+                        if (lim < 32) nw <<= (32 - lim);
+                        nsw[w] = nw;
+                        S ^= __popc(nw) & 1u;
+                    }
                 }
                 // sign of every outgoing message = (product of all signs) * own sign, ldpc.py:190
-                uint32_t S = parity_of<ST>(ns);
                 if (a.sign_mode == LDPC_SIGN_CORRECTED) S ^= (uint32_t)deg & 1u;
-                const ST full = (deg >= (int)(8 * sizeof(ST))) ? ~(ST)0 : ((((ST)1) << deg) - 1);
-                ns ^= S ? full : (ST)0;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) {
+                    const int lim = deg - 32 * w;
+                    const uint32_t full = lim >= 32 ? 0xffffffffu : lim > 0 ? 0xffffffffu << (32 - lim) : 0u;
+                    nsw[w] ^= S ? full : 0u;
+                }
                 min1 = ms_correct(min1, a.ms_alpha, a.ms_beta);
                 min2 = ms_correct(min2, a.ms_alpha, a.ms_beta);
                 T2 mm; mm.x = min1; mm.y = min2;
                 mins[slot] = mm;
-                Meta mt; mt.signs = ns; mt.idx = idx;
-                meta[slot] = mt;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) meta[slot * MW + w] = nsw[w];
+                meta[slot * MW + NW] = idx;
                 if (synd != 0ull) flags[par * FPW + f] = 1;
             }
             __syncthreads();
@@ -413,7 +475,11 @@ qc_minsum_kernel(const QcTables tb, const DecodeArgs a)
             if (act_mask == 0) break;
             // the row's messages of this iteration become its "previous" messages only now:
             // a frame that stops here keeps the ones its last completed iteration sent
-            if (((act_mask >> f) & 1u) && live) { omin1 = min1; omin2 = min2; osigns = ns; oidx = idx; }
+            if (((act_mask >> f) & 1u) && live) {
+                omin1 = min1; omin2 = min2; oidx = idx;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) osw[w] = nsw[w];
+            }
             if (tid < FPW) flags[(par ^ 1) * FPW + tid] = 0;
             // ================= variable pass (ldpc.py:295-311, 321-323)
             if (((act_mask >> f) & 1u) && live) {
@@ -431,29 +497,53 @@ qc_minsum_kernel(const QcTables tb, const DecodeArgs a)
                                 const int2 en = ent[0];
                                 uint32_t r = (uint32_t)(i - en.x);
                                 r = min(r, r + (uint32_t)Z);
-                                acc = acc + rebuild<T, S64>(mins[rbase + (int)r], meta[rbase + (int)r], en.y);
+                                acc = acc + rebuild_row<T, S64>(mins, meta, rbase + (int)r, en.y);
                             } else if (cg.y == 2) {
                                 const int2 hi = ent[0], lo = ent[1];     // hi.x > lo.x
                                 uint32_t rh = (uint32_t)(i - hi.x); rh = min(rh, rh + (uint32_t)Z);
                                 uint32_t rl = (uint32_t)(i - lo.x); rl = min(rl, rl + (uint32_t)Z);
-                                const T vh = rebuild<T, S64>(mins[rbase + (int)rh], meta[rbase + (int)rh], hi.y);
-                                const T vl = rebuild<T, S64>(mins[rbase + (int)rl], meta[rbase + (int)rl], lo.y);
+                                const T vh = rebuild_row<T, S64>(mins, meta, rbase + (int)rh, hi.y);
+                                const T vl = rebuild_row<T, S64>(mins, meta, rbase + (int)rl, lo.y);
                                 // smaller row index first: the low shift's row comes first
                                 // exactly when lo.x <= i < hi.x
                                 const bool lo_first = (i >= lo.x) && (i < hi.x);
                                 acc = acc + (lo_first ? vl : vh);
                                 acc = acc + (lo_first ? vh : vl);
+                            } else if (cg.y <= 8) {
+                                // Shifts descending: the rows i - s of the shifts s <= i ascend, then the rows i - s + Z
+                                // of the shifts s > i, which are the first `wrapped` entries.  All messages are fetched
+                                // first (their LDS latencies overlap), then added in that order; an entry that is not
+                                // its pass's turn adds +0, which changes no sum (x + 0 == x; a partial sum of -0 that
+                                // becomes +0 meets a channel value that is never -0 in the end).
+                                T v[8];
+                                int wrapped = 0;
+#pragma unroll
+                                for (int k = 0; k < 8; ++k) {
+                                    v[k] = T(0);
+                                    if (k < cg.y) {                      // uniform
+                                        const int2 en = ent[k];
+                                        int r = i - en.x;
+                                        const bool wr = r < 0;
+                                        r += wr ? Z : 0;
+                                        wrapped += wr ? 1 : 0;
+                                        v[k] = rebuild_row<T, S64>(mins, meta, rbase + r, en.y);
+                                    }
+                                }
+#pragma unroll
+                                for (int k = 0; k < 8; ++k) acc = acc + (k >= wrapped ? v[k] : T(0));
+#pragma unroll
+                                for (int k = 0; k < 8; ++k) acc = acc + (k < wrapped ? v[k] : T(0));
                             } else {
                                 // shifts descending: rows i - s (s <= i) ascend, then rows i - s + Z (s > i) ascend
                                 for (int k = 0; k < cg.y; ++k) {
                                     const int2 en = ent[k];
                                     if (en.x <= i)
-                                        acc = acc + rebuild<T, S64>(mins[rbase + i - en.x], meta[rbase + i - en.x], en.y);
+                                        acc = acc + rebuild_row<T, S64>(mins, meta, rbase + i - en.x, en.y);
                                 }
                                 for (int k = 0; k < cg.y; ++k) {
                                     const int2 en = ent[k];
                                     if (en.x > i)
-                                        acc = acc + rebuild<T, S64>(mins[rbase + i - en.x + Z], meta[rbase + i - en.x + Z], en.y);
+                                        acc = acc + rebuild_row<T, S64>(mins, meta, rbase + i - en.x + Z, en.y);
                                 }
                             }
                         }
@@ -498,8 +588,9 @@ qc_minsum_kernel(const QcTables tb, const DecodeArgs a)
     if (a.chain && live) {
         T2 mm; mm.x = omin1; mm.y = omin2;
         chain_mins[slot] = mm;
-        Meta mt; mt.signs = osigns; mt.idx = oidx;
-        chain_meta[slot] = mt;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) chain_meta[slot * MW + w] = osw[w];
+        chain_meta[slot * MW + NW] = oidx;
     }
 }
 
@@ -1680,7 +1771,7 @@ static size_t qc_lds_bytes(const QcTables &tb)
     const size_t slots = (size_t)FPW * tb.mb * tb.Zp;
     size_t b = (((size_t)FPW * tb.n * sizeof(T)) + 15) & ~(size_t)15;
     b += slots * sizeof(typename Vec2<T>::type);
-    b += slots * sizeof(typename SignBits<S64>::Meta);
+    b += (slots * (size_t)RowMeta<S64>::MW * 4 + 15) & ~(size_t)15;
     b += 3 * FPW * sizeof(int);
     b = (b + 15) & ~(size_t)15;
     b += qc_table_bytes(tb);
