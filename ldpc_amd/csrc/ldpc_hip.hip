@@ -1022,7 +1022,7 @@ accumulate_kernel(int64_t n_frames, int n, float sigma, const int32_t *iters, co
             if (conv[f] == 0) atomicAdd(&c[5], 1ull);
             if (per_frame) {
                 float *p = per_frame + 4 * f;
-                p[0] = awgn_sigma_hat(sumsq[f], points.sigma[pt], n);
+                p[0] = sumsq ? awgn_sigma_hat(sumsq[f], points.sigma[pt], n) : sigma_hat[f];
                 p[1] = (float)uncoded[f];
                 p[2] = (float)ones[f];
                 p[3] = (float)iters[f];
@@ -2504,8 +2504,10 @@ extern "C" int ldpc_eval_awgn(ldpc_handle *h, int algo, int prec, int sign_mode,
     // time is that of its slowest frame, and with most of the card idle the points can run side by side.
     // Same noise per (point, frame) as one launch per point (LDPC_HIP_NO_POINT_BATCH=1, a test hook).
     const char *unbatched = hook("LDPC_HIP_NO_POINT_BATCH");
-    const bool batched = fused && n_snr > 1 && n_snr <= GEN_MAX_POINTS && frames_per_snr * n_snr <= GEN_MAX_BATCH &&
-                         !(unbatched && unbatched[0] == '1');
+    // (Kernels that read their channel values take part when the points share one LLR scale -- min-sum: the
+    // channel kernel then fills one buffer point after point, and one decode launch reads it.)
+    const bool batched = (fused || algo == LDPC_ALGO_MINSUM) && n_snr > 1 && n_snr <= GEN_MAX_POINTS &&
+                         frames_per_snr * n_snr <= GEN_MAX_BATCH && !(unbatched && unbatched[0] == '1');
     const int64_t cap = fused ? ((int64_t)1 << 24) : (int64_t)(((size_t)8192 << 20) / (n * 4)) + 1;
     const int64_t chunk = batched ? frames_per_snr * n_snr : std::max<int64_t>(1, std::min<int64_t>(frames_per_snr, cap));
     if (batched && (rc = select_launch(h, algo, prec, chunk, false, &L))) return rc;      // grid for all the points' frames
@@ -2547,6 +2549,16 @@ extern "C" int ldpc_eval_awgn(ldpc_handle *h, int algo, int prec, int sign_mode,
                         a.gen_point_scale[q] = algo == LDPC_ALGO_SUMPRODUCT ? (float)(4.0 * pow(10.0, snr_db[q] / 10.0)) : 1.0f;
                     }
                 }
+            } else if (batched) {
+                for (int q = 0; q < n_snr; ++q) {
+                    const size_t at = (size_t)q * (size_t)frames_per_snr;
+                    if ((rc = launch_channel(h, snr_db[q], seed, (uint32_t)q, first_frame, frames_per_snr,
+                                             reinterpret_cast<float *>(h->b_llr.p) + at * n,
+                                             reinterpret_cast<float *>(h->b_sig.p) + at,
+                                             reinterpret_cast<int32_t *>(h->b_unc.p) + at)))
+                        return rc;
+                }
+                a.llr = h->b_llr.p;
             } else {
                 if ((rc = launch_channel(h, snr_db[s], seed, (uint32_t)s, first_frame + (uint64_t)f0, nf,
                                          reinterpret_cast<float *>(h->b_llr.p),
@@ -2567,7 +2579,7 @@ extern "C" int ldpc_eval_awgn(ldpc_handle *h, int algo, int prec, int sign_mode,
                                fused ? reinterpret_cast<const unsigned long long *>(h->b_sq.p) : nullptr,
                                reinterpret_cast<unsigned long long *>(h->b_cnt.p) + 6 * s,
                                per_frame ? reinterpret_cast<float *>(h->b_pf.p) : nullptr,
-                               a.gen_per_point, ps);
+                               batched ? (uint32_t)frames_per_snr : 0u, ps);
             HIP_TRY(hipGetLastError());
             if (per_frame)
                 HIP_TRY(hipMemcpyAsync(per_frame + ((size_t)s * frames_per_snr + f0) * 4, h->b_pf.p,

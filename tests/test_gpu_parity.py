@@ -571,7 +571,8 @@ def test_small_sweep_in_one_launch_equals_one_launch_per_point(monkeypatch):
     import ldpc_amd
     from ldpc_amd import codes
     base = codes.near_earth()
-    for code in (base, base.with_block(1, 4, [3, 77, 200, 401, 500])):
+    many, _ = build_code('nearEarth_mut_many')       # table-driven kernel: reads its channel values, batched all the same
+    for code in (base, base.with_block(1, 4, [3, 77, 200, 401, 500]), many, codes.wifi_1944('1/2')):
         with ldpc_amd.Decoder(code) as eng:
             for algo in (0, 1):
                 for snrs, F, first in (([3.0, 3.2, 3.4], 10, 0), ([2.5, 3.0, 3.5, 4.0, 4.5, 5.0, 5.5, 6.0], 1024, 999),
@@ -586,7 +587,6 @@ def test_small_sweep_in_one_launch_equals_one_launch_per_point(monkeypatch):
                     assert (c1[:, 0] == F).all()
             # without per-frame output, and a sweep too large to batch
             c1, _ = eng.eval_awgn([3.0, 3.4], 300, seed=2)
-            c3, _ = eng.eval_awgn([3.4], 300, seed=2)
             assert c1[1, 0] == 300 and c1[0, 4] > c1[1, 4]
             c4, _ = eng.eval_awgn([3.0, 3.4], 5000, seed=2)
             assert (c4[:, 0] == 5000).all()

@@ -42,6 +42,28 @@ def main():
             ts = np.array(ts) * 1e3
             out['kinds'][f'{kind}, {"device" if rng else "host (reference)"} noise'] = {
                 'p50_ms': float(np.percentile(ts, 50)), 'p99_ms': float(np.percentile(ts, 99)), 'mean_ms': float(ts.mean())}
+    # An episode as the environment runs it: every action's circulant stays (ldpc_env.py:293-317), so the state
+    # grows heavier step by step -- past the message-plane kernels' limits after a few actions, to checks of
+    # 60 ... 100 edges after 40.
+    ev = gym_eval.CodeEvaluator(seed=3, deviceRng=True)
+    ev.step(base)
+    ts, degs = [], []
+    for ep in range(3):
+        state = base
+        for k in range(40):
+            w = int(prng.randint(1, 8))
+            state = state.with_block(int(prng.randint(2)), int(prng.randint(16)), sorted(prng.choice(511, w, replace=False).tolist()))
+            t0 = time.perf_counter()
+            ev.step(state)
+            ts.append(time.perf_counter() - t0)
+            degs.append(max(state.row_degrees()))
+    ts = np.array(ts) * 1e3
+    degs = np.array(degs)
+    out['episode'] = {'what': '3 episodes of 40 actions from NearEarth, shift lists, device noise; the state keeps every action',
+                      'p50_ms': float(np.percentile(ts, 50)), 'p99_ms': float(np.percentile(ts, 99)), 'mean_ms': float(ts.mean()),
+                      'mean_ms_first_5_actions': float(ts.reshape(3, 40)[:, :5].mean()),
+                      'mean_ms_last_10_actions': float(ts.reshape(3, 40)[:, 30:].mean()),
+                      'largest_check_degree_at_the_end': int(degs.reshape(3, 40)[:, -1].max())}
     # where the time goes for a dense matrix
     H = cands[0].to_dense()
     t = {}
