@@ -75,6 +75,18 @@ int ldpc_create_qc(int device, int Z, int mb, int nb, const int32_t *blk_ptr,
                    const int32_t *shifts, ldpc_handle **out);
 
 /*
+ * Host helper: the shift lists (ldpc_create_qc's blk_ptr / shifts) of a dense row-major matrix whose
+ * entries are elem_bytes = 1, 4 or 8 bytes wide (any non-zero pattern counts as 1; a float64 matrix of
+ * 0.0 / 1.0 qualifies), if it is block-circulant with circulants of size Z.  The reference hands its
+ * decoders the dense matrix (ldpc.py:225-247, ldpc_env.py:370).  Returns 0 and fills blk_ptr
+ * [(m/Z)*(n/Z)+1] and shifts [<= shifts_cap] (ascending inside a block), 1 if the matrix is not
+ * block-circulant with this Z, a negative code for bad arguments or too small a shifts array.
+ * No device is touched.
+ */
+int ldpc_dense_to_qc(const void *H, int elem_bytes, int m, int n, int Z, int32_t *blk_ptr,
+                     int32_t *shifts, int shifts_cap);
+
+/*
  * Build a decoder for an arbitrary sparse H given as CSR (row_ptr[m+1],
  * col_idx ascending inside a row).  Replaces ldpcDecoder.__init__
  * (ldpc.py:225-247) for matrices that are not block-circulant.  Any check

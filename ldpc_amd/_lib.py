@@ -12,6 +12,7 @@ SYMBOLS = (
     'ldpc_reset_state', 'ldpc_decode_device', 'ldpc_decode_device_noalloc',
     'ldpc_channel_awgn_device', 'ldpc_eval_awgn', 'ldpc_get_launch_info',
     'ldpc_comm_unique_id', 'ldpc_comm_create', 'ldpc_comm_destroy', 'ldpc_allreduce_counters',
+    'ldpc_dense_to_qc',
 )
 
 _lib = None
@@ -98,6 +99,8 @@ def load():
     L.ldpc_get_launch_info.restype = i32
     L.ldpc_get_launch_info.argtypes = [vp, i32, i32, c.POINTER(i32), c.POINTER(i32), c.POINTER(i32),
                                        c.POINTER(i32)]
+    L.ldpc_dense_to_qc.restype = i32
+    L.ldpc_dense_to_qc.argtypes = [vp, i32, i32, i32, i32, vp, vp, i32]
     L.ldpc_comm_unique_id.restype = i32
     L.ldpc_comm_unique_id.argtypes = [vp]
     L.ldpc_comm_create.restype = i32

