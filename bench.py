@@ -211,6 +211,14 @@ def secondary(eng, llr, F, args, hard, iters, conv, ones, stream, dev):
         with ldpc_amd.Decoder(code, device=eng.device) as e2:
             e2.set_stream(stream.cuda_stream)
             timed(name + ', corrected sign rule, %.1f dB' % args.snr, e2, llr, Fm, K_INFO, prec=32, sign_mode=ldpc_amd.SIGN_CORRECTED)
+    # the state of a gym episode after 40 actions (the environment keeps every action's circulant): beyond the
+    # message-plane kernels' limits, on the table-driven kernel; a poor code, so most frames run all iterations
+    late = codes.gym_episode_state(base, 40, seed=20211227)
+    with ldpc_amd.Decoder(late, device=eng.device) as e2:
+        e2.set_stream(stream.cuda_stream)
+        timed('NearEarth after a gym episode of 40 actions (checks of %s edges), min-sum float32, corrected sign rule, %.1f dB'
+              % (' and '.join(str(d) for d in late.row_degrees()), args.snr), e2, llr, min(F, 20000), K_INFO, prec=32,
+              sign_mode=ldpc_amd.SIGN_CORRECTED)
     # 802.11n n = 1944 codes (corrected sign rule: the reference's rule does not decode odd check degrees)
     for rate, qc in codes.wifi_1944_all().items():
         with ldpc_amd.Decoder(qc, device=eng.device) as e2:

@@ -231,6 +231,19 @@ def detect_qc(H, candidates=None):
     return None
 
 
+def gym_episode_state(base, n_actions, seed):
+    """The code after n_actions steps of the gym environment from `base`: every action replaces one
+    circulant by one with 1 ... 7 hot bits and the state keeps them all (ldpc_env.py:293-317;
+    hot-bit budget: models.py:296, 368).  Synthetic actions from RandomState(seed), for benchmarks."""
+    prng = np.random.RandomState(seed)
+    state = base
+    for _ in range(int(n_actions)):
+        w = int(prng.randint(1, 8))
+        state = state.with_block(int(prng.randint(base.mb)), int(prng.randint(base.nb)),
+                                 sorted(prng.choice(base.Z, w, replace=False).tolist()))
+    return state
+
+
 def dense_to_csr(H):
     """(m, n, row_ptr int32[m+1], col_idx int32[E]) with ascending columns per row,
     the adjacency ldpcDecoder.__init__ derives with np.where (ldpc.py:237-247)."""
