@@ -9,7 +9,9 @@ rows -- so that every kernel family of the library is reached (message planes wi
 short-code kernels with fixed and with packed records, the table-driven kernel with sign words of 32, 64 and 128
 bits, the edge-list kernels with compressed rows and with one message per edge), and for each draws a batch of
 channel values (some frames clean, some with erased stretches, some hopeless), an iteration budget, a sign
-rule, a precision and a mode (fresh decoder per frame, re-used decoder, min-sum scaling, sum-product).  The
+rule, a precision and a mode (fresh decoder per frame, re-used decoder, min-sum scaling, sum-product; the
+device and allocation-free entry points against the host entry point; the sweep driver's launch forms against
+each other).  The
 library's results must equal the CPU oracle's bit for bit (sum-product, whose transcendentals are not pinned:
 the frames the oracle converges are counted, identical or not, and reported).
 Prints one progress line every few cases and a JSON summary at the end; exits non-zero at the first mismatch,
@@ -122,7 +124,7 @@ def main():
         budget = int(prng.choice([0, 1, 2, 5, 12, 50]))
         prec = int(prng.choice([32, 64]))
         sm = int(prng.randint(2))
-        mode = ['fresh', 'fresh', 'chained', 'scaled', 'spa'][prng.randint(5)]
+        mode = ['fresh', 'fresh', 'chained', 'scaled', 'spa', 'device', 'sweep'][prng.randint(7)]
         dt = np.float64 if prec == 64 else np.float32
         orc = om.Oracle(H)
         params = dict(code=label, m=m, n=n, frames=F, snr=snr, budget=budget, prec=prec, sign_mode=sm, mode=mode)
@@ -145,6 +147,50 @@ def main():
                     if cv.sum() and same.mean() < stats.get('spa_worst_case', (1.0, ''))[0]:
                         stats['spa_worst_case'] = (float(same.mean()), json.dumps(params))
                     ok = True
+                elif mode == 'device':
+                    # device entry points (plain and allocation-free) against the host entry point, which the
+                    # other modes pin to the oracle
+                    import torch
+                    algo = int(prng.randint(2)) if prec == 32 else 0
+                    want = eng.decode(Y, budget, prec=prec, sign_mode=sm, want_soft=True, algo=algo)
+                    d = torch.from_numpy(Y).cuda()
+                    ok = True
+                    for noalloc in (False, True):
+                        hard = torch.zeros((F, eng.nbytes), dtype=torch.uint8, device='cuda')
+                        it_ = torch.zeros(F, dtype=torch.int32, device='cuda')
+                        cv_ = torch.zeros(F, dtype=torch.uint8, device='cuda')
+                        on_ = torch.zeros(F, dtype=torch.int32, device='cuda')
+                        soft = torch.zeros((F, n), dtype=torch.float64 if prec == 64 else torch.float32, device='cuda')
+                        try:
+                            eng.decode_device(d, F, budget, prec=prec, algo=algo, sign_mode=sm, d_hard=hard, d_iters=it_,
+                                              d_conv=cv_, d_ones=on_, d_soft=soft, noalloc=noalloc)
+                        except ldpc_amd.LdpcHipError as e:
+                            if noalloc and ('workspace' in str(e) or 'edge tables' in str(e)):
+                                stats['noalloc_refused'] = stats.get('noalloc_refused', 0) + 1
+                                continue
+                            raise
+                        torch.cuda.synchronize()
+                        bits = np.unpackbits(hard.cpu().numpy(), axis=1, bitorder='little')[:, :n]
+                        ok = ok and (np.array_equal(bits, want['hard']) and np.array_equal(it_.cpu().numpy(), want['iters']) and
+                                     np.array_equal(cv_.cpu().numpy(), want['converged']) and np.array_equal(on_.cpu().numpy(), want['ones']) and
+                                     np.array_equal(soft.cpu().numpy(), want['soft']))
+                elif mode == 'sweep':
+                    # the sweep driver: one launch for all points against one launch per point, noise made inside the
+                    # decode kernel against the channel kernel into a buffer
+                    snrs = [float(x) for x in prng.choice([1.0, 2.5, 3.5, 5.0, 7.0], int(prng.randint(1, 5)), replace=False)]
+                    algo = int(prng.randint(2)) if prec == 32 else 0
+                    kw = dict(seed=int(prng.randint(1, 1 << 30)), first_frame=int(prng.randint(1000)), max_iters=budget, prec=prec,
+                              algo=algo, sign_mode=sm, per_frame=True)
+                    outs = []
+                    for env in ({}, {'LDPC_HIP_NO_POINT_BATCH': '1'}, {'LDPC_HIP_NO_FUSED_CHANNEL': '1', 'LDPC_HIP_NO_POINT_BATCH': '1'}):
+                        for k_ in ('LDPC_HIP_NO_POINT_BATCH', 'LDPC_HIP_NO_FUSED_CHANNEL'):
+                            os.environ.pop(k_, None)
+                        os.environ.update(env)
+                        outs.append(eng.eval_awgn(snrs, F, **kw))
+                    for k_ in ('LDPC_HIP_NO_POINT_BATCH', 'LDPC_HIP_NO_FUSED_CHANNEL'):
+                        os.environ.pop(k_, None)
+                    ok = all(np.array_equal(outs[0][0], o[0]) and np.array_equal(outs[0][1], o[1]) for o in outs[1:])
+                    ok = ok and bool((outs[0][0][:, 0] == F).all())
                 elif mode == 'chained':
                     # A re-used decoder that never converges feeds its messages back frame after frame; after some
                     # tens of frames they overflow (the reference's would too, ldpc.py:270-274, 356).  What min / med3
@@ -180,7 +226,7 @@ def main():
             print('MISMATCH', json.dumps(params), flush=True)
             if args.out:
                 extra = {}
-                if mode not in ('spa',) and 'error' not in params:
+                if mode not in ('spa', 'device', 'sweep') and 'error' not in params:
                     extra = dict(want_iters=iters, want_conv=conv, want_hard=hard, got_iters=r['iters'], got_conv=r['converged'],
                                  got_hard=r['hard'])
                 np.savez_compressed(args.out + '.case.npz', H=H.astype(np.uint8), Y=Y, **extra)
