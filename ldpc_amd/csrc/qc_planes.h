@@ -653,18 +653,29 @@ planes_role(unsigned char *smem, const PlanesTables &tb, const DecodeArgs &a)
             sigma = a.gen_point_sigma[pt];
             scale = a.gen_point_scale[pt];
         }
+        // Round keys come from the seed by scalar additions where they are used.  Left loop-invariant they
+        // are 20 values held across the whole decode, which the register allocator parks in lanes of a
+        // vector register and fetches back one by one (a fifth of this function's vector instructions).
+        uint32_t seed_lo = (uint32_t)a.gen_seed, seed_hi = (uint32_t)(a.gen_seed >> 32);
+        asm volatile("" : "+s"(seed_lo), "+s"(seed_hi));
+        enum { NCALL = (N / 4 + NT - 1) / NT };
+        uint32_t qb[NCALL];
+        float4 zc[NCALL];
 #pragma unroll
-        for (int hh = 0; hh < (N / 4 + NT - 1) / NT; ++hh) {
-            const uint32_t qb = (uint32_t)tid + (uint32_t)hh * NT;
-            if (qb < (uint32_t)(N / 4)) {
-                const float4 z = normal4(a.gen_seed, noise_frame, qb, noise_stream);
-                const float zz[4] = {z.x, z.y, z.z, z.w};
+        for (int hh = 0; hh < NCALL; ++hh) qb[hh] = (uint32_t)tid + (uint32_t)hh * NT;
+        normal4_calls<NCALL>(seed_lo, seed_hi, noise_frame, qb, noise_stream, zc);   // calls beyond the frame's end: made, not used
+#pragma unroll
+        for (int hh = 0; hh < NCALL; ++hh) {
+            if (qb[hh] < (uint32_t)(N / 4)) {
+                const float zz[4] = {zc[hh].x, zc[hh].y, zc[hh].z, zc[hh].w};
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const float yv = -1.0f + sigma * zz[k];
                     sq += awgn_sq_fixed(zz[k]);
                     err += (int)__popcll(__ballot(yv > 0.f));
-                    lds_put_f32(smem, (4u * qb + (uint32_t)k) * CB, yv * scale + 0.0f);
+                    // no "+ 0" as for values that come from memory: yv is never -0.0 (a sum is -0.0 only if
+                    // both terms are) and |yv| >= 2^-24 or 0, so the product cannot be -0.0 either
+                    lds_put_f32(smem, (4u * qb[hh] + (uint32_t)k) * CB, yv * scale);
                 }
             }
         }

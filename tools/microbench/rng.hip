@@ -24,6 +24,20 @@ __device__ __forceinline__ uint4 philox(uint4 c, uint2 k)
     return c;
 }
 
+// The same rounds with each product taken as one 64-bit multiply (v_mad_u64_u32 gives both halves).
+template <int ROUNDS>
+__device__ __forceinline__ uint4 philox_wide(uint4 c, uint2 k)
+{
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c.x, p1 = (uint64_t)0xCD9E8D57u * c.z;
+        c = make_uint4((uint32_t)(p1 >> 32) ^ c.y ^ k.x, (uint32_t)p1, (uint32_t)(p0 >> 32) ^ c.w ^ k.y, (uint32_t)p0);
+        k.x += 0x9E3779B9u;
+        k.y += 0xBB67AE85u;
+    }
+    return c;
+}
+
 __device__ __forceinline__ uint32_t rotl(uint32_t x, int r) { return __builtin_amdgcn_alignbit(x, x, 32 - r); }
 
 template <int ROUNDS>
@@ -49,7 +63,7 @@ __device__ __forceinline__ uint4 threefry(uint4 c, uint4 k)
     return make_uint4(x0, x1, x2, x3);
 }
 
-__device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+__device__ __forceinline__ float u01(uint32_t x) { return __builtin_fmaf((float)(x >> 8), 1.0f / 16777216.0f, 0.5f / 16777216.0f); }
 __device__ __forceinline__ float4 box_muller(uint4 r)
 {
     const float r0 = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u01(r.x)));
@@ -59,7 +73,8 @@ __device__ __forceinline__ float4 box_muller(uint4 r)
                        r1 * __builtin_amdgcn_cosf(a1), r1 * __builtin_amdgcn_sinf(a1));
 }
 
-// MODE 0 philox-10, 1 philox-7, 2 threefry-20, 3 threefry-12, 4 box-muller only, 5 philox-10 + box-muller, 6 threefry-20 + box-muller
+// MODE 0 philox-10, 1 philox-7, 2 threefry-20, 3 threefry-12, 4 box-muller only, 5 philox-10 + box-muller, 6 threefry-20 + box-muller,
+// 7 philox-10 on 64-bit products, 8 the same + box-muller
 template <int MODE>
 __global__ void __launch_bounds__(THREADS) rng_kernel(float *out, unsigned long long *cycles, uint32_t seed)
 {
@@ -75,8 +90,9 @@ __global__ void __launch_bounds__(THREADS) rng_kernel(float *out, unsigned long 
         if (MODE == 1) r = philox<7>(c, make_uint2(seed, 7));
         if (MODE == 2 || MODE == 6) r = threefry<20>(c, make_uint4(seed, 7, 0, 0));
         if (MODE == 3) r = threefry<12>(c, make_uint4(seed, 7, 0, 0));
+        if (MODE == 7 || MODE == 8) r = philox_wide<10>(c, make_uint2(seed, 7));
         if (MODE == 4) r = make_uint4(c.x * 2654435761u, c.x ^ 0x9E3779B9u, c.x + 0x12345u, c.x * 3u);
-        if (MODE >= 4) {
+        if (MODE >= 4 && MODE != 7) {
             const float4 z = box_muller(r);
             facc += (z.x + z.y) + (z.z + z.w);
         } else {
@@ -99,10 +115,11 @@ int main()
     unsigned long long *cyc;
     CHECK(hipMalloc(&out, sizeof(float) * THREADS * blocks));
     CHECK(hipMalloc(&cyc, sizeof(unsigned long long) * blocks));
-    const char *names[7] = {"philox4x32_10", "philox4x32_7", "threefry4x32_20", "threefry4x32_12", "box_muller_4",
-                            "philox4x32_10+box_muller", "threefry4x32_20+box_muller"};
+    const char *names[9] = {"philox4x32_10", "philox4x32_7", "threefry4x32_20", "threefry4x32_12", "box_muller_4",
+                            "philox4x32_10+box_muller", "threefry4x32_20+box_muller", "philox4x32_10_mad64",
+                            "philox4x32_10_mad64+box_muller"};
     printf("{");
-    for (int mode = 0; mode < 7; ++mode) {
+    for (int mode = 0; mode < 9; ++mode) {
         for (int rep = 0; rep < 2; ++rep) {
             switch (mode) {
             case 0: hipLaunchKernelGGL(rng_kernel<0>, dim3(blocks), dim3(THREADS), 0, 0, out, cyc, 1u); break;
@@ -111,7 +128,9 @@ int main()
             case 3: hipLaunchKernelGGL(rng_kernel<3>, dim3(blocks), dim3(THREADS), 0, 0, out, cyc, 1u); break;
             case 4: hipLaunchKernelGGL(rng_kernel<4>, dim3(blocks), dim3(THREADS), 0, 0, out, cyc, 1u); break;
             case 5: hipLaunchKernelGGL(rng_kernel<5>, dim3(blocks), dim3(THREADS), 0, 0, out, cyc, 1u); break;
-            default: hipLaunchKernelGGL(rng_kernel<6>, dim3(blocks), dim3(THREADS), 0, 0, out, cyc, 1u); break;
+            case 6: hipLaunchKernelGGL(rng_kernel<6>, dim3(blocks), dim3(THREADS), 0, 0, out, cyc, 1u); break;
+            case 7: hipLaunchKernelGGL(rng_kernel<7>, dim3(blocks), dim3(THREADS), 0, 0, out, cyc, 1u); break;
+            default: hipLaunchKernelGGL(rng_kernel<8>, dim3(blocks), dim3(THREADS), 0, 0, out, cyc, 1u); break;
             }
             CHECK(hipDeviceSynchronize());
         }
