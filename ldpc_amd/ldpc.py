@@ -330,6 +330,26 @@ def testNearEarth(numOfTransmissions=50):
     return bStats
 
 
+def testWifi(numOfTransmissions=50):
+    """ldpc.py:504-525, the 802.11n n = 1944 rate 5/6 code over the same SNR points.  The reference marks
+    it decommissioned: its evaluation call is commented out, so it stops at `return bStats` with a
+    NameError; here the call its NearEarth twin makes (ldpc.py:495) is made for the WiFi matrix."""
+    print("*** in test wifi")
+    wifiParity = codes.wifi_1944_r56()
+    roi = [3.0, 3.2, 3.4, 3.6]
+    codewordSize = 1944
+    messageSize = 1620
+    numOfIterations = 50
+    start = time.time()
+    bStats = testCodeUsingMultiprocessing(460101, roi, messageSize, codewordSize, numOfIterations,
+                                          numOfTransmissions, wifiParity)
+    end = time.time()
+    print('Time it took for code evaluation == %d' % (end - start))
+    print('Throughput == ' + str((codewordSize * len(roi) * numOfTransmissions) / max(end - start, 1e-12))
+          + 'bits per second.')
+    return bStats
+
+
 def main():
     print("*** In ldpc.py main function.")
     return testNearEarth()

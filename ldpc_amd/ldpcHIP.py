@@ -86,6 +86,23 @@ def _evaluate_on(eng, seed, SNRpoints, numberOfIterations, numOfTransmissions, p
     return berStats
 
 
+def evaluateMatrixAndEpsilon(parityMatrix, epsilon, numberOfIterations=50, cudaDeviceNumber=0, prec=32):
+    """One frame with the caller's noise vector (ldpcCUDA.py:677-828): the all-zero codeword,
+    modulated to -1 (float32, ldpcCUDA.py:504-507), plus `epsilon`; returns
+    (berUncoded, berDecoded, iterator, totalTime) -- channel hard-decision errors, errors left after
+    decoding, iterations run, seconds spent decoding.  `iterator` is the exact count, as everywhere
+    in this module (the reference looks at its stop flag every sixth iteration, ldpcCUDA.py:774-776)."""
+    n_dev = max(device_count(), 1)
+    with _ldpc._engine_lease(parityMatrix, cudaDeviceNumber, cudaDeviceNumber % n_dev) as eng:
+        fromChannel = np.full(eng.n, -1, dtype=np.float32) + np.asarray(epsilon).reshape(eng.n)
+        berUncoded = int(np.count_nonzero(fromChannel > 0))          # slicer, ldpcCUDA.py:497-501
+        start = time.time()
+        r = eng.decode(np.asarray(fromChannel, dtype=np.float64 if prec == 64 else np.float32).reshape(1, eng.n),
+                       numberOfIterations, prec=prec, want_hard=False)
+        totalTime = time.time() - start
+    return berUncoded, int(r['ones'][0]), int(r['iters'][0]), totalTime
+
+
 def evaluateCodeCudaWrapper(seeds, SNRpoints, numberOfIterations, parityMatrix, numOfTransmissions, G='None',
                             numberOfCudaDevices=4, prec=32, deviceRng=False):
     """numOfTransmissions // numberOfCudaDevices frames per device, device d seeded with
@@ -101,6 +118,20 @@ def evaluateCodeCudaWrapper(seeds, SNRpoints, numberOfIterations, parityMatrix, 
         for f in futs:
             berStats = berStats.add(f.result())
     return berStats
+
+
+def testConcurrentFutures(numberOfCudaDevices=1, prec=32):
+    """ldpcCUDA.testConcurrentFutures (ldpcCUDA.py:871-888): 15 NearEarth frames per SNR point on every
+    device, device d seeded with the d-th draw of RandomState(7134066).randint(0, 2**31 - 1), rows
+    concatenated in device order.  (As shipped the reference's function stops with a NameError: the
+    generator and its bounds are locals of evaluateCodeCuda, ldpcCUDA.py:47-49; this is what it spells out.)"""
+    nearEarthParity = codes.near_earth()
+    numOfTransmissions = 15
+    roi = [3.0, 3.2, 3.4, 3.6]
+    numOfIterations = 50
+    seeds = np.random.RandomState(7134066).randint(0, 2 ** 31 - 1, numberOfCudaDevices, dtype=np.int64)
+    return evaluateCodeCudaWrapper(seeds, roi, numOfIterations, nearEarthParity,
+                                   numOfTransmissions * numberOfCudaDevices, 'None', numberOfCudaDevices, prec=prec)
 
 
 def testNearEarth(numOfTransmissions=60, graphics=False, prec=32):

@@ -96,6 +96,11 @@ def test_evaluateCode_and_multiprocessing_mirror(oracle_mod):
     rows2 = bs2.getRawStats()
     assert len(rows2) == 8 and rows2 == sorted(rows2)
     assert all(r[4] == 1 and r[5] == 0 and r[8] == 'Codeword' for r in rows2)   # flipped first symbol is corrected
+    # testWifi (ldpc.py:504-525, with the evaluation call its NearEarth twin makes): 4 points x 3 frames
+    rows3 = ldpc.testWifi(3).getRawStats()
+    assert len(rows3) == 12 and rows3 == sorted(rows3)
+    assert [r[0] for r in rows3[::3]] == [3.0, 3.2, 3.4, 3.6]
+    assert all(r[4] == 1 and r[5] == 0 and r[7] == 50 and r[8] == 'Codeword' for r in rows3)
 
 
 def test_evaluateCodeCuda_matches_oracle_on_host_seeded_frames(oracle_mod):
@@ -127,6 +132,20 @@ def test_evaluateCodeCuda_matches_oracle_on_host_seeded_frames(oracle_mod):
     assert [tuple(r[:8]) for r in rw[:12]] == [tuple(r[:8]) for r in rows]
     st, status = ldpcHIP.testNearEarth(8)
     assert status == 'OK'
+    # evaluateMatrixAndEpsilon (ldpcCUDA.py:677-828): one frame, the caller's noise
+    eps = np.float32(np.random.RandomState(99).normal(0, np.sqrt(0.5 / 10 ** 0.32), 8176))
+    y = np.float32(-1) + eps
+    hard, iters, conv, _ = orc.minsum(y, 50, prec=32)
+    unc, dec, it, seconds = ldpcHIP.evaluateMatrixAndEpsilon(H, eps)
+    assert (unc, dec, it) == (np.count_nonzero(y > 0), hard.sum(), iters[0]) and unc > 0 and seconds > 0
+    # ldpcCUDA.testConcurrentFutures (ldpcCUDA.py:871-888): 15 frames per point and device, seeds from RandomState(7134066)
+    two = ldpcHIP.testConcurrentFutures(2).getRawStats()
+    dseeds = np.random.RandomState(7134066).randint(0, 2 ** 31 - 1, 2, dtype=np.int64)
+    roi = [3.0, 3.2, 3.4, 3.6]
+    assert len(two) == 2 * 4 * 15
+    for d in range(2):
+        one = ldpcHIP.evaluateCodeCuda(dseeds[d], roi, 50, H, 15).getRawStats()
+        assert [tuple(r[:8]) for r in two[60 * d:60 * (d + 1)]] == [tuple(r[:8]) for r in one]
 
 
 def test_device_rng_evaluation_statistics():

@@ -285,3 +285,45 @@ def test_generator_file_parsing_follows_the_reference(tmp_path):
     good.write_text('A5A\n0F\n')
     with pytest.raises(ValueError):
         codes.parse_generator_file(str(good), Z, Z)
+
+
+def test_mirror_modules_keep_the_reference_signatures():
+    """Names and leading parameters of the reference's entry points on the path (ldpc.py:43-66, 350-532;
+    ldpcCUDA.py:40, 677, 832, 871, 891; common.py:142), so that a caller's positional and keyword
+    arguments land where they did."""
+    import inspect
+    from ldpc_amd import ldpc, ldpcHIP, common, fileHandler, wifiMatrices
+    want = {
+        ldpc: {
+            'slicer': ['vector', 'length'], 'modulate': ['vector', 'length'], 'addAWGN': ['vector', 'length', 'SNRdb', 'prng'],
+            'evaluateCode': ['numberOfTransmissions', 'seed', 'SNRpoints', 'messageSize', 'codewordSize',
+                             'numberOfIterations', 'H', 'G'],
+            'evaluateCodeAtSingleTransmission': ['seed', 'SNRpoints', 'messageSize', 'codewordSize',
+                                                 'numberOfIterations', 'H', 'G'],
+            'testCodeUsingMultiprocessing': ['seed', 'SNRpoints', 'messageSize', 'codewordSize', 'numberOfIterations',
+                                             'numberOfTransmissions', 'H', 'method', 'reference', 'G'],
+            'testNearEarth': ['numOfTransmissions'], 'testWifi': ['numOfTransmissions'], 'main': [],
+            'testModulationAndSlicingRoundTrip': [], 'constantFunction': ['const'],
+        },
+        ldpcHIP: {
+            'evaluateCodeCuda': ['seed', 'SNRpoints', 'numberOfIterations', 'parityMatrix', 'numOfTransmissions', 'G',
+                                 'cudaDeviceNumber'],
+            'evaluateMatrixAndEpsilon': ['parityMatrix', 'epsilon', 'numberOfIterations', 'cudaDeviceNumber'],
+            'evaluateCodeCudaWrapper': ['seeds', 'SNRpoints', 'numberOfIterations', 'parityMatrix', 'numOfTransmissions',
+                                        'G', 'numberOfCudaDevices'],
+            'testNearEarth': ['numOfTransmissions', 'graphics'], 'testConcurrentFutures': ['numberOfCudaDevices'],
+        },
+        common: {'recursiveLinearFit': ['xData', 'yData', 'numberOfIterations', 'earlyStopping'], 'berStatistics': None},
+        fileHandler: {'readMatrixFromFile': ['fileName', 'dim0', 'dim1', 'circulantSize', 'isRow', 'isHex', 'isGenerator']},
+        wifiMatrices: {'getWifiParityMatrix': ['codewordSize', 'circulantSize', 'rate']},
+    }
+    for mod, names in want.items():
+        for name, params in names.items():
+            fn = getattr(mod, name)
+            if params is not None:
+                got = list(inspect.signature(fn).parameters)
+                assert got[:len(params)] == params, (mod.__name__, name, got)
+    for method in ('isCodeword', 'decoderMainLoop'):
+        assert callable(getattr(ldpc.ldpcDecoder, method))
+    for method in ('addEntry', 'getStats', 'getStatsV2', 'add', 'union', 'getRawStats'):
+        assert callable(getattr(common.berStatistics, method))
