@@ -148,6 +148,29 @@ def test_evaluateCodeCuda_matches_oracle_on_host_seeded_frames(oracle_mod):
         assert [tuple(r[:8]) for r in two[60 * d:60 * (d + 1)]] == [tuple(r[:8]) for r in one]
 
 
+def test_wifiCUDA_mirror(oracle_mod):
+    """wifiCUDA.evaluateCodeCuda / testWifi (wifiCUDA.py:496-682) on the 802.11n matrix: rows equal to the
+    float32 oracle's on the frames the reference would draw."""
+    from ldpc_amd import wifiHIP, wifiMatrices
+    H = wifiMatrices.getWifiParityMatrix()
+    orc = oracle_mod.Oracle(np.asarray(H))
+    rows = wifiHIP.evaluateCodeCuda(460101, [3.0, 3.6], 50, H, 5).getRawStats()
+    prng = np.random.RandomState(460101)
+    k = 0
+    for snr in (3.0, 3.6):
+        sigma = np.sqrt(0.5 / 10 ** (snr / 10))
+        for _ in range(5):
+            y = np.float32(-1) + np.float32(prng.normal(0, sigma, 1944))
+            hard, iters, conv, _ = orc.minsum(y, 50, prec=32)
+            r = rows[k]
+            assert (r[0], r[4], r[5], r[6], r[7]) == (snr, np.count_nonzero(y > 0), hard.sum(), iters[0], 50)
+            k += 1
+    st, status = wifiHIP.testWifi(6)
+    assert len(st.getRawStats()) == 24 and status in ('OK', 'WIFI problem')
+    a, b, c, d = st.getStats(1944)
+    assert status == ('OK' if c[2] == 0 and c[3] == 0 else 'WIFI problem')
+
+
 def test_device_rng_evaluation_statistics():
     from ldpc_amd import ldpcHIP, codes
     bs = ldpcHIP.evaluateCodeCuda(5, [3.0, 3.4, 3.8], 50, codes.near_earth(), 200, deviceRng=True)

@@ -289,10 +289,10 @@ def test_generator_file_parsing_follows_the_reference(tmp_path):
 
 def test_mirror_modules_keep_the_reference_signatures():
     """Names and leading parameters of the reference's entry points on the path (ldpc.py:43-66, 350-532;
-    ldpcCUDA.py:40, 677, 832, 871, 891; common.py:142), so that a caller's positional and keyword
+    ldpcCUDA.py:40, 677, 832, 871, 891; wifiCUDA.py:496, 660; common.py:142), so that a caller's positional and keyword
     arguments land where they did."""
     import inspect
-    from ldpc_amd import ldpc, ldpcHIP, common, fileHandler, wifiMatrices
+    from ldpc_amd import ldpc, ldpcHIP, wifiHIP, common, fileHandler, wifiMatrices
     want = {
         ldpc: {
             'slicer': ['vector', 'length'], 'modulate': ['vector', 'length'], 'addAWGN': ['vector', 'length', 'SNRdb', 'prng'],
@@ -312,6 +312,10 @@ def test_mirror_modules_keep_the_reference_signatures():
             'evaluateCodeCudaWrapper': ['seeds', 'SNRpoints', 'numberOfIterations', 'parityMatrix', 'numOfTransmissions',
                                         'G', 'numberOfCudaDevices'],
             'testNearEarth': ['numOfTransmissions', 'graphics'], 'testConcurrentFutures': ['numberOfCudaDevices'],
+        },
+        wifiHIP: {
+            'evaluateCodeCuda': ['seed', 'SNRpoints', 'numberOfIterations', 'parityMatrix', 'numOfTransmissions', 'G'],
+            'testWifi': ['numOfTransmissions'], 'main': [],
         },
         common: {'recursiveLinearFit': ['xData', 'yData', 'numberOfIterations', 'earlyStopping'], 'berStatistics': None},
         fileHandler: {'readMatrixFromFile': ['fileName', 'dim0', 'dim1', 'circulantSize', 'isRow', 'isHex', 'isGenerator']},
