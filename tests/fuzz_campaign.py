@@ -216,9 +216,18 @@ def main():
                     eng.set_minsum_scaling(alpha, beta)
                     hard, iters, conv, soft = orc.minsum(Y.astype(dt), budget, prec=prec, sign_mode=sm, alpha=alpha, beta=beta, threads=8)
                     r = eng.decode(Y, budget, prec=prec, sign_mode=sm, want_soft=True)
+                    # A frame that never converges on a code full of 4-cycles (a circulant of weight 9) multiplies its
+                    # messages by up to 8 per iteration and leaves float32 after some 44 of them (float64, the
+                    # reference's CPU arithmetic, does not get there in 50).  Up to and including the first infinities
+                    # the kernels and the oracle agree; what min / med3 make of the NaNs that follow is not part of the
+                    # contract, so a frame the oracle ends with a non-finite posterior is compared in its iteration
+                    # count and status only.
+                    fin = np.isfinite(soft).all(axis=1)
+                    if not fin.all():
+                        stats['overflowed_frames'] = stats.get('overflowed_frames', 0) + int((~fin).sum())
                     ok = (np.array_equal(r['iters'], iters) and np.array_equal(r['converged'], conv) and
-                          np.array_equal(r['hard'], hard) and np.array_equal(r['soft'], soft) and
-                          np.array_equal(r['ones'], hard.sum(1)))
+                          np.array_equal(r['hard'][fin], hard[fin]) and np.array_equal(r['soft'][fin], soft[fin]) and
+                          np.array_equal(r['ones'][fin], hard[fin].sum(1)))
         except ldpc_amd.LdpcHipError as e:
             params['error'] = str(e)
             ok = False
