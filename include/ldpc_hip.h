@@ -140,6 +140,11 @@ int ldpc_sync(ldpc_handle *h);
  *              the posterior vector decoderMainLoop returns (ldpc.py:337)
  * prec: 32 = float32 arithmetic (the reference's GPU path, ldpcCUDA.py:538-548),
  *       64 = float64 arithmetic (the reference's CPU path, ldpc.py:29).
+ *       The rule has no normalisation: on a code full of 4-cycles (a circulant of weight 9, say)
+ *       a frame that never converges grows its messages by up to (column degree - 1) per iteration
+ *       and can leave float32 within 50 iterations; its soft values and hard decisions are then
+ *       infinities / NaNs as in any float32 implementation of the rule (iteration count and
+ *       status stay meaningful).  float64 has the range the reference relies on.
  * Synchronous.  Replaces ldpcDecoder.decoderMainLoop (ldpc.py:326-337) and the
  * per-frame body of ldpcCUDA.evaluateCodeCuda (ldpcCUDA.py:583-662).
  */
