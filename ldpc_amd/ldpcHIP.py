@@ -63,11 +63,14 @@ def evaluateCodeCuda(seed, SNRpoints, numberOfIterations, parityMatrix, numOfTra
         return _evaluate_on(eng, seed, SNRpoints, numberOfIterations, numOfTransmissions, prec, deviceRng)
 
 
-def _evaluate_on(eng, seed, SNRpoints, numberOfIterations, numOfTransmissions, prec, deviceRng):
+def _evaluate_on(eng, seed, SNRpoints, numberOfIterations, numOfTransmissions, prec, deviceRng, budget=None):
+    """budget: iterations the decoder may run when that is not the number reported in the rows
+    (wifiCUDA.py:535, 579, 646)."""
     n = eng.n
+    budget = numberOfIterations if budget is None else budget
     berStats = common.berStatistics()
     if deviceRng:
-        cnt, pf = eng.eval_awgn(list(SNRpoints), numOfTransmissions, int(seed), max_iters=numberOfIterations,
+        cnt, pf = eng.eval_awgn(list(SNRpoints), numOfTransmissions, int(seed), max_iters=budget,
                                 prec=prec, per_frame=True)
         for s in range(len(SNRpoints)):
             sigma = np.sqrt(0.5 / (10 ** (SNRpoints[s] / 10)))
@@ -79,7 +82,7 @@ def _evaluate_on(eng, seed, SNRpoints, numberOfIterations, numOfTransmissions, p
     localPrng = np.random.RandomState(seed)
     Y, meta = _noise_frames(localPrng, SNRpoints, numOfTransmissions, n)
     if len(meta):
-        r = eng.decode(Y, numberOfIterations, prec=prec, want_hard=False)
+        r = eng.decode(Y, budget, prec=prec, want_hard=False)
         for k, (snr, sigma, sigmaActual, berUncoded) in enumerate(meta):
             berStats.addEntry(snr, sigma, sigmaActual, berUncoded, int(r['ones'][k]), int(r['iters'][k]),
                               numberOfIterations, 'test')

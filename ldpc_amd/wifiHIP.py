@@ -10,13 +10,23 @@ vector per frame, wifiCUDA.py:472-481, 503, 553).
 import time
 
 from . import ldpcHIP, wifiMatrices
+from . import ldpc as _ldpc
+from .engine import device_count
+
+MAX_NUMBER_OF_ITERATIONS = 40        # wifiCUDA.py:535
 
 
 def evaluateCodeCuda(seed, SNRpoints, numberOfIterations, parityMatrix, numOfTransmissions, G='None',
                      cudaDeviceNumber=0, prec=32, deviceRng=False):
-    """wifiCUDA.evaluateCodeCuda (wifiCUDA.py:496-657); the device argument is this package's addition."""
-    return ldpcHIP.evaluateCodeCuda(seed, SNRpoints, numberOfIterations, parityMatrix, numOfTransmissions, G,
-                                    cudaDeviceNumber, prec, deviceRng)
+    """wifiCUDA.evaluateCodeCuda (wifiCUDA.py:496-657).  As there, the decoder runs at most 40 iterations
+    whatever `numberOfIterations` says (wifiCUDA.py:535, 579); the argument is only written into the rows
+    (wifiCUDA.py:646).  The device argument is this package's addition."""
+    assert (seed > 0)
+    assert hasattr(SNRpoints, "__len__")
+    n_dev = max(device_count(), 1)
+    with _ldpc._engine_lease(parityMatrix, cudaDeviceNumber, cudaDeviceNumber % n_dev) as eng:
+        return ldpcHIP._evaluate_on(eng, seed, SNRpoints, numberOfIterations, numOfTransmissions, prec, deviceRng,
+                                    budget=MAX_NUMBER_OF_ITERATIONS)
 
 
 def testWifi(numOfTransmissions=50):

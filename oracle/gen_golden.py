@@ -221,15 +221,55 @@ def gen_chained():
     np.savez_compressed(os.path.join(OUT, 'chained_decoder.npz'), **out)
 
 
+def gen_wifi_rows():
+    """berStatistics rows of the reference's evaluateCodeAtSingleTransmission (ldpc.py:391-430) on its 802.11n
+    matrix, the call ldpc.testWifi (ldpc.py:504-525) would make through testCodeUsingMultiprocessing: the codeword
+    with its first symbol flipped (ldpc.py:417-418), decoded under the reference's sign rule on rows of odd degree."""
+    ref = load_reference()
+    import wifiMatrices
+    H = np.array(wifiMatrices.getWifiParityMatrix(), dtype=np.int32)
+    bs = ref.evaluateCodeAtSingleTransmission(460101, [3.0, 3.2, 3.4, 3.6], 1620, 1944, 50, H)
+    rows = bs.getRawStats()
+    num = np.array([[float(x) for x in row[:8]] for row in rows], dtype=np.float64)
+    status = np.array([row[8] for row in rows])
+    np.savez_compressed(os.path.join(OUT, 'berstats_single_transmission_wifi.npz'), rows=num, status=status)
+    print('berStatistics rows (802.11n):', num.tolist(), status.tolist())
+
+
+def gen_evaluate_code_rows():
+    """berStatistics rows of the reference's evaluateCode (ldpc.py:350-388) on a freshly loaded module: 3 frames at
+    each of three SNR points (the first low enough that frames fail and leave their messages behind for the next
+    frame), noise from the module's own generator (ldpc.py:24, 372), ONE decoder object for all nine frames
+    (ldpc.py:356, 377)."""
+    ref = load_reference()
+    import fileHandler
+    H = np.array(fileHandler.readMatrixFromFile(os.path.join(REF, 'codeMatrices', 'nearEarthParity.txt'),
+                                                1022, 8176, 511, True, False, False), dtype=np.int32)
+    bs = ref.evaluateCode(3, 17, [2.6, 3.4, 4.0], 7154, 8176, 50, H)
+    rows = bs.getRawStats()
+    num = np.array([[float(x) for x in row[:8]] for row in rows], dtype=np.float64)
+    status = np.array([row[8] for row in rows])
+    np.savez_compressed(os.path.join(OUT, 'berstats_evaluate_code.npz'), rows=num, status=status)
+    print('evaluateCode rows:', num.tolist(), status.tolist())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--quick', action='store_true', help='2 frames per point (plumbing check)')
     ap.add_argument('--jobs', type=int, default=8)
     ap.add_argument('--only-chained', action='store_true', help='only (re)generate chained_decoder.npz')
     ap.add_argument('--only', default=None, help='only (re)generate the file of this code, e.g. nearEarth_mut_many')
+    ap.add_argument('--only-evaluate-code-rows', action='store_true', help='only (re)generate berstats_evaluate_code.npz')
+    ap.add_argument('--only-wifi-rows', action='store_true', help='only (re)generate berstats_single_transmission_wifi.npz')
     args = ap.parse_args()
     nf = 2 if args.quick else None
     os.makedirs(OUT, exist_ok=True)
+    if args.only_wifi_rows:
+        gen_wifi_rows()
+        return
+    if args.only_evaluate_code_rows:
+        gen_evaluate_code_rows()
+        return
     if not args.only:
         gen_chained()
     if args.only_chained:
@@ -325,6 +365,8 @@ def main():
                         rows=num, status=status,
                         **{f'v2_{i}': np.asarray(a) for i, a in enumerate(v2)})
     print('berStatistics rows:', num.tolist(), status.tolist())
+    gen_wifi_rows()
+    gen_evaluate_code_rows()
 
 
 if __name__ == '__main__':

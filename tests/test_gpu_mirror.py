@@ -92,6 +92,13 @@ def test_evaluateCode_and_multiprocessing_mirror(oracle_mod):
             assert r[4] == 0 and r[5] == hard.sum() and r[6] == iters[0]
             assert r[8] == ('Codeword' if conv[0] else 'Not a codeword')
             k += 1
+    # the same call the reference itself answered (oracle/gen_golden.py --only-evaluate-code-rows): nine frames on one
+    # decoder, the first three fail and leave their messages behind -- all nine columns of every row
+    importlib.reload(ldpc)
+    g = np.load(os.path.join(GOLDEN, 'berstats_evaluate_code.npz'))
+    rows9 = ldpc.evaluateCode(3, 17, [2.6, 3.4, 4.0], 7154, 8176, 50, H).getRawStats()
+    assert np.array_equal(np.array([[float(x) for x in r[:8]] for r in rows9]), g['rows'])
+    assert [r[8] for r in rows9] == [str(x) for x in g['status']]
     bs2 = ldpc.testCodeUsingMultiprocessing(460101, [3.0, 3.2], 7154, 8176, 50, 4, H)
     rows2 = bs2.getRawStats()
     assert len(rows2) == 8 and rows2 == sorted(rows2)
@@ -100,15 +107,22 @@ def test_evaluateCode_and_multiprocessing_mirror(oracle_mod):
     rows3 = ldpc.testWifi(3).getRawStats()
     assert len(rows3) == 12 and rows3 == sorted(rows3)
     assert [r[0] for r in rows3[::3]] == [3.0, 3.2, 3.4, 3.6]
-    # every row decodes the same input, the codeword with its first symbol flipped (ldpc.py:417-418); what comes out
-    # is the reference's rule on rows of odd degree (ldpc.py:135-141), i.e. what the oracle says, not a corrected word
-    from ldpc_amd import wifiMatrices
-    y = -np.ones(1944)
-    y[0] = 1.0
-    hard, iters, conv, _ = oracle_mod.Oracle(np.asarray(wifiMatrices.getWifiParityMatrix())).minsum(y, 50, prec=64)
+    # every row decodes the same input, the codeword with its first symbol flipped (ldpc.py:417-418); under the
+    # reference's rule on rows of odd degree (ldpc.py:135-141) it is NOT corrected: the fixture holds what the
+    # reference itself returns for this matrix (oracle/gen_golden.py --only-wifi-rows)
+    g = np.load(os.path.join(GOLDEN, 'berstats_single_transmission_wifi.npz'))
+    assert [r[0] for r in rows3[::3]] == g['rows'][:, 0].tolist()
     for r in rows3:
-        assert r[4] == 1 and r[7] == 50
-        assert (r[5], r[6], r[8]) == (hard.sum(), iters[0], 'Codeword' if conv[0] else 'Not a codeword')
+        assert [float(x) for x in r[4:8]] == g['rows'][0, 4:8].tolist() == [1.0, 1.0, 50.0, 50.0]
+        assert r[8] == str(g['status'][0]) == 'Not a codeword'
+    # and the single-transmission call itself, all columns (module PRNG back to its seed, ldpc.py:24)
+    importlib.reload(ldpc)
+    from ldpc_amd import wifiMatrices
+    bs = ldpc.evaluateCodeAtSingleTransmission(460101, [3.0, 3.2, 3.4, 3.6], 1620, 1944, 50,
+                                               wifiMatrices.getWifiParityMatrix())
+    rows4 = bs.getRawStats()
+    assert np.array_equal(np.array([[float(x) for x in r[:8]] for r in rows4]), g['rows'])
+    assert [r[8] for r in rows4] == [str(x) for x in g['status']]
 
 
 def test_evaluateCodeCuda_matches_oracle_on_host_seeded_frames(oracle_mod):
@@ -162,17 +176,18 @@ def test_wifiCUDA_mirror(oracle_mod):
     from ldpc_amd import wifiHIP, wifiMatrices
     H = wifiMatrices.getWifiParityMatrix()
     orc = oracle_mod.Oracle(np.asarray(H))
-    rows = wifiHIP.evaluateCodeCuda(460101, [3.0, 3.6], 50, H, 5).getRawStats()
+    rows = wifiHIP.evaluateCodeCuda(460101, [1.0, 3.6], 50, H, 5).getRawStats()        # 1 dB: frames that use the whole budget
     prng = np.random.RandomState(460101)
     k = 0
-    for snr in (3.0, 3.6):
+    for snr in (1.0, 3.6):
         sigma = np.sqrt(0.5 / 10 ** (snr / 10))
         for _ in range(5):
             y = np.float32(-1) + np.float32(prng.normal(0, sigma, 1944))
-            hard, iters, conv, _ = orc.minsum(y, 50, prec=32)
+            hard, iters, conv, _ = orc.minsum(y, 40, prec=32)        # 40 whatever the argument says, wifiCUDA.py:535
             r = rows[k]
             assert (r[0], r[4], r[5], r[6], r[7]) == (snr, np.count_nonzero(y > 0), hard.sum(), iters[0], 50)
             k += 1
+    assert max(r[6] for r in rows) == 40
     st, status = wifiHIP.testWifi(6)
     assert len(st.getRawStats()) == 24 and status in ('OK', 'WIFI problem')
     a, b, c, d = st.getStats(1944)

@@ -101,3 +101,40 @@ def test_oracle_edge_cases(oracle_mod):
     # empty batch
     hard, iters, conv, soft = orc.minsum(np.zeros((0, n)), 50, prec=64)
     assert hard.shape == (0, n) and iters.shape == (0,)
+
+
+def test_oracle_on_the_reference_single_transmission_rows_for_wifi(oracle_mod):
+    """evaluateCodeAtSingleTransmission of the reference on its 802.11n matrix (ldpc.py:391-430; fixture from
+    oracle/gen_golden.py --only-wifi-rows): the codeword with its first symbol flipped stays undecoded for all 50
+    iterations under the reference's sign rule on rows of odd degree.  The oracle says the same."""
+    import os
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, 'berstats_single_transmission_wifi.npz'))
+    qc, H = build_code('wifi_5_6')
+    y = -np.ones(1944)
+    y[0] = 1.0
+    hard, iters, conv, _ = oracle_mod.Oracle(H).minsum(y, 50, prec=64)
+    for row, status in zip(g['rows'], g['status']):
+        assert row[4] == 1 and row[5] == hard.sum() and row[6] == iters[0] and row[7] == 50
+        assert str(status) == ('Codeword' if conv[0] else 'Not a codeword')
+
+
+def test_oracle_on_the_reference_evaluateCode_rows(oracle_mod):
+    """ldpc.evaluateCode of the reference itself (ldpc.py:350-388; fixture from oracle/gen_golden.py
+    --only-evaluate-code-rows): nine frames on ONE decoder object, the first three failing and leaving their
+    messages behind.  The oracle with carried state reproduces error counts, iteration counts and status."""
+    import os
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, 'berstats_evaluate_code.npz'))
+    qc, H = build_code('nearEarth')
+    orc = oracle_mod.Oracle(H)
+    prng = np.random.RandomState(7134066)            # the module's generator, ldpc.py:24
+    state = orc.new_state(64)
+    for row, status in zip(g['rows'], g['status']):
+        sigma = np.sqrt(0.5 / 10 ** (row[0] / 10))
+        noise = prng.normal(0, sigma, 8176)
+        assert row[2] == sigma and row[3] == np.sqrt(np.sum(noise ** 2) / 8176)
+        hard, iters, conv, _ = orc.minsum(-1.0 + noise, 50, prec=64, state=state)
+        assert (row[5], row[6], row[7]) == (hard.sum(), iters[0], 50)
+        assert str(status) == ('Codeword' if conv[0] else 'Not a codeword')
+    assert g['rows'][:3, 5].min() > 0 and (g['rows'][3:, 5] == 0).all()
