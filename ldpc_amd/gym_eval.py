@@ -59,3 +59,156 @@ class CodeEvaluator:
             H = codes.observation_to_qc(H)
         berStats = self.evaluateCode(H)
         return self.calcReward(berStats), berStats
+
+
+class LdpcEnv:
+    """The environment object of the reference (LdpcEnv, ldpc_env.py:49-407) as far as it drives the
+    evaluation path: the same constructor arguments, attributes, `reset`, `step(action)`,
+    `replaceCirculant`, `evaluateCode`, `calcReward`, `compress` / `uncompress`, with the state kept as
+    per-circulant shift lists instead of a dense 1022 x 8176 array (`state` builds the dense matrix on
+    request).  A step therefore hands the engine 2 x 16 short lists, not 8.4 million matrix entries.
+    It is a plain object: no gym base class, spaces or rendering (ldpc_env.py:100-107, 286-288).
+
+    Reproduced as they are: every action is legal (the coordinate test of ldpc_env.py:306 cannot fail
+    for 1 + 4 coordinate bits), `done` stays False (the accumulated decoding time is never updated,
+    ldpc_env.py:260, 372-375), and in `replacementOnly` mode the source block is read at
+    (xr, xr) and, through NumPy views, ends up in both (x, y) and (xr, yr) (ldpc_env.py:191-196)."""
+
+    def __init__(self, replacementOnly=False, seed=7134066, numberOfCudaDevices=4, resetHammingDistance='MAXIMUM',
+                 prec=32, deviceRng=False):
+        from . import codes
+        self.replacementOnly = replacementOnly
+        self.messageSize = 7156                                        # sic, ldpc_env.py:84
+        self.codewordSize = 8176
+        self.SNRpoints = np.array([3.0, 3.2, 3.4], dtype=np.float32)
+        self.BERpoints = np.ones(len(self.SNRpoints), dtype=np.float32)
+        self.resetValue = codes.near_earth()
+        self._code = self.resetValue
+        self.circulantSize = 511
+        self.xBits = 1
+        self.yBits = 4
+        self.actionBits = (self.xBits + self.yBits + self.circulantSize if not replacementOnly
+                           else 2 * self.xBits + 2 * self.yBits)
+        self.observationUint8 = 2048
+        self.ldpcDecoderNumOfIterations = LDPC_ENV_NUMBER_OF_ITERATIONS
+        self.ldpcDecoderNumOfTransmissions = LDPC_ENV_NUMBER_OF_TRANSMISSIONS
+        self.xCoordinateBinaryToInt = np.flipud(2 ** np.arange(self.xBits))
+        self.yCoordinateBinaryToInt = np.flipud(2 ** np.arange(self.yBits))
+        self.seed = seed
+        self.rewardForIllegalAction = -2.0
+        self.rewardForBadCandidate = -2.0
+        self.scatterSnr = self.SNRpoints
+        self.scatterBer = self.BERpoints
+        self.scatterItr = np.ones(len(self.SNRpoints), dtype=np.float32)
+        self.accumulatedEvaluationTime = 0
+        self.berStats = common.berStatistics()
+        self.pConst = np.poly1d([1])
+        self.localPRNG = np.random.RandomState(seed)
+        self.cudaDevices = numberOfCudaDevices
+        self.resetHammingDistance = resetHammingDistance
+        self._evaluator = CodeEvaluator(SNRpoints=self.SNRpoints, numberOfIterations=self.ldpcDecoderNumOfIterations,
+                                        numberOfTransmissions=self.ldpcDecoderNumOfTransmissions,
+                                        numberOfDevices=numberOfCudaDevices,
+                                        rewardForBadCandidate=self.rewardForBadCandidate, prec=prec, deviceRng=deviceRng)
+        self._evaluator.localPRNG = self.localPRNG                      # one generator, as in the reference
+        self.observed_state = self.compress()
+
+    # ---- state
+    @property
+    def code(self):
+        """The current parity-check matrix as shift lists (ldpc_amd.codes.QCCode)."""
+        return self._code
+
+    @property
+    def state(self):
+        """The dense matrix the reference keeps in `self.state` (built on request)."""
+        return self._code.to_dense()
+
+    def reset(self):
+        """ldpc_env.py:267-284"""
+        self._code = self.resetValue
+        self.observed_state = self.compress()
+        self.BERpoints = np.ones(len(self.SNRpoints), dtype=np.float32)
+        self.accumulatedEvaluationTime = 0
+        return self.observed_state
+
+    def replaceCirculant(self, xCoordinate, yCoordinate, newCirculant):
+        """ldpc_env.py:293-317.  newCirculant: a Z x Z circulant matrix (row i = row 0 rotated right by i,
+        what `circulant(firstRow).T` is), or the hot positions of its first row."""
+        if (xCoordinate > (2 ** self.xBits)) or (yCoordinate > (2 ** self.yBits)):
+            return 'Illegal action'
+        c = np.asarray(newCirculant)
+        hot = np.flatnonzero(c[0]) if c.ndim == 2 else c.astype(np.int64)
+        self._code = self._code.with_block(int(xCoordinate), int(yCoordinate), sorted(int(s) for s in hot))
+        return 'OK'
+
+    def step(self, action):
+        """ldpc_env.py:169-264 -> (observation, reward, done, {})"""
+        done = False
+        action = np.asarray(action)
+        assert (action.shape[0] == self.actionBits if self.replacementOnly
+                else action.shape[0] == self.xBits + self.yBits + self.circulantSize)
+        xCoordinate = int(self.xCoordinateBinaryToInt.dot(action[0:self.xBits]))
+        yCoordinate = int(self.yCoordinateBinaryToInt.dot(action[self.xBits:self.xBits + self.yBits]))
+        if self.replacementOnly:
+            o = self.xBits + self.yBits
+            xrCoordinate = int(self.xCoordinateBinaryToInt.dot(action[o:o + self.xBits]))
+            yrCoordinate = int(self.yCoordinateBinaryToInt.dot(action[o + self.xBits:o + self.xBits + self.yBits]))
+            source = self._code.blocks[xrCoordinate][xrCoordinate]       # (xr, xr), ldpc_env.py:192
+            status = self.replaceCirculant(xCoordinate, yCoordinate, np.asarray(source, dtype=np.int64))
+            if status == 'OK':
+                # the reference passes a view of block (x, y), which by now holds the new content
+                status = self.replaceCirculant(xrCoordinate, yrCoordinate,
+                                               np.asarray(self._code.blocks[xCoordinate][yCoordinate], dtype=np.int64))
+            else:
+                status = 'FAILED'
+        else:
+            circulantFirstRow = action[self.xBits + self.yBits:]
+            status = self.replaceCirculant(xCoordinate, yCoordinate, np.flatnonzero(circulantFirstRow))
+        if status == 'OK':
+            self.berStats = self.evaluateCode()
+            (self.scatterSnr, self.scatterBer, self.scatterItr, snrAxis, averageSnrAxis, berData,
+             averageNumberOfIterations) = self.berStats.getStatsV2()
+            self.BERpoints = berData
+            reward = self.calcReward()
+        else:
+            reward = self.rewardForIllegalAction
+        self.observed_state = self.compress()
+        return self.observed_state, reward, done, {}
+
+    def evaluateCode(self):
+        """ldpc_env.py:353-377"""
+        return self._evaluator.evaluateCode(self._code)
+
+    def calcReward(self, colour=None):
+        """ldpc_env.py:319-345"""
+        if len(self.BERpoints) < 2:
+            return self.rewardForBadCandidate
+        snr, ber, p1, trendP, itr = common.recursiveLinearFit(self.scatterSnr, self.scatterBer)
+        pTotalInteg = (self.pConst - p1).integ()
+        return pTotalInteg(self.SNRpoints[-1]) - pTotalInteg(self.SNRpoints[0])
+
+    def compress(self):
+        """ldpc_env.py:379-394: rows 0 and 511 of the matrix, a zero bit after every 511, packed to 2 x 1024 bytes.
+        Row 0 of a block has its ones at the block's shifts."""
+        rows = []
+        for b in range(2):
+            padded = np.zeros(8192, dtype=np.uint8)
+            for j in range(16):
+                sh = np.asarray(self._code.blocks[b][j], dtype=np.int64)
+                padded[j * 512 + sh] = 1
+            rows.append(np.packbits(padded))
+        self.observed_state = np.hstack(rows)
+        return self.observed_state
+
+    def uncompress(self):
+        """ldpc_env.py:396-401 -> (row 0, row 511) of the matrix, 8176 bits each"""
+        half = len(self.observed_state) // 2
+        mask = np.ones(8192, dtype=bool)
+        mask[(np.arange(16) + 1) * 512 - 1] = False
+        return np.unpackbits(self.observed_state[:half])[mask], np.unpackbits(self.observed_state[half:])[mask]
+
+    def constantFunction(self, alpha):
+        def g(x):
+            return alpha
+        return g

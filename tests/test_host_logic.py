@@ -331,3 +331,51 @@ def test_mirror_modules_keep_the_reference_signatures():
         assert callable(getattr(ldpc.ldpcDecoder, method))
     for method in ('addEntry', 'getStats', 'getStatsV2', 'add', 'union', 'getRawStats'):
         assert callable(getattr(common.berStatistics, method))
+
+
+def test_LdpcEnv_state_transitions_follow_the_reference_step():
+    """LdpcEnv.step / replaceCirculant / compress / reset (ldpc_env.py:169-317, 379-401) on shift lists against the
+    same statements made on the dense matrix with NumPy, views included; the evaluation is stubbed (no device)."""
+    from scipy.linalg import circulant
+    from ldpc_amd import gym_eval, common
+    prng = np.random.RandomState(5)
+
+    def stub(env):
+        bs = common.berStatistics()
+        for s in env.SNRpoints:
+            for t in range(3):
+                bs.addEntry(float(s), 0.5, 0.5, 300, int(prng.randint(0, 200)), 50, 50, 'test')
+        return bs
+
+    env = gym_eval.LdpcEnv(numberOfCudaDevices=1)
+    env.evaluateCode = lambda: stub(env)
+    dense = env.state.copy()
+    assert env.actionBits == 516 and env.observed_state.shape == (2048,)
+    for _ in range(4):
+        action = np.zeros(516, dtype=np.int32)
+        action[:5] = prng.randint(0, 2, 5)
+        action[5 + prng.choice(511, prng.randint(0, 8), replace=False)] = 1
+        x, y = int(action[0]), int(action[1:5].dot([8, 4, 2, 1]))
+        dense[x * 511:(x + 1) * 511, y * 511:(y + 1) * 511] = circulant(action[5:]).T          # ldpc_env.py:208-209, 313
+        obs, reward, done, info = env.step(action)
+        assert np.array_equal(env.state, dense) and np.array_equal(obs, common.compress(dense))
+        assert done is False and info == {} and np.isfinite(reward)
+        r0, r1 = env.uncompress()
+        assert np.array_equal(r0, dense[0]) and np.array_equal(r1, dense[511])
+    assert np.array_equal(env.reset(), common.compress(env.resetValue.to_dense()))
+
+    env = gym_eval.LdpcEnv(replacementOnly=True, numberOfCudaDevices=1)
+    env.evaluateCode = lambda: stub(env)
+    env.replaceCirculant(1, 1, [4, 9, 200])                      # make block (1, 1) something recognisable
+    dense = env.state.copy()
+    assert env.actionBits == 10
+    for bits in ([0, 0, 0, 1, 1, 1, 0, 1, 0, 1], [1, 0, 0, 0, 1, 0, 1, 1, 1, 1], [0, 1, 1, 1, 1, 0, 0, 0, 0, 0]):
+        a = np.array(bits, dtype=np.int32)
+        x, y, xr, yr = int(a[0]), int(a[1:5].dot([8, 4, 2, 1])), int(a[5]), int(a[6:10].dot([8, 4, 2, 1]))
+        Z = 511
+        xy = dense[x * Z:(x + 1) * Z, y * Z:(y + 1) * Z]                                        # views, ldpc_env.py:191-192
+        xryr = dense[xr * Z:(xr + 1) * Z, xr * Z:(xr + 1) * Z]
+        dense[x * Z:(x + 1) * Z, y * Z:(y + 1) * Z] = xryr
+        dense[xr * Z:(xr + 1) * Z, yr * Z:(yr + 1) * Z] = xy
+        env.step(a)
+        assert np.array_equal(env.state, dense)
