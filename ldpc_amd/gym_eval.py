@@ -212,3 +212,25 @@ class LdpcEnv:
         def g(x):
             return alpha
         return g
+
+
+def testCompressionRoundrip():
+    """ldpc_env.py:410-418: the observation unpacks to rows 0 and 511 of the state, 1000 random states.  The
+    reference draws unstructured random matrices (only the two rows matter to it); here the state is block-circulant
+    by construction, so every round installs random circulants."""
+    testEnvironment = LdpcEnv(numberOfCudaDevices=1)
+    prng = np.random.RandomState(1)
+    for i in range(1000):
+        firstRow, secondRow = testEnvironment.uncompress()
+        dense0 = np.zeros(8176, dtype=np.uint8)
+        dense1 = np.zeros(8176, dtype=np.uint8)
+        for j in range(16):
+            dense0[j * 511 + np.asarray(testEnvironment.code.blocks[0][j], dtype=np.int64)] = 1
+            dense1[j * 511 + np.asarray(testEnvironment.code.blocks[1][j], dtype=np.int64)] = 1
+        assert np.all(firstRow == dense0), "First row does not match"
+        assert np.all(secondRow == dense1), "Second row does not match"
+        for _ in range(3):
+            testEnvironment.replaceCirculant(int(prng.randint(2)), int(prng.randint(16)),
+                                             prng.choice(511, int(prng.randint(0, 9)), replace=False))
+        testEnvironment.observed_state = testEnvironment.compress()
+    return 'OK'
