@@ -71,6 +71,12 @@ planes_load_frame(const void *llr, int is_f64, int64_t frame_base, uint32_t firs
 #ifndef PLANES_PRIO
 #define PLANES_PRIO 1               // 0: no priority staging in the check pass (5 % slower; kept for comparison)
 #endif
+#ifndef PLANES_ARGMIN_FSUB
+#define PLANES_ARGMIN_FSUB 1        // 0: arg-min bits through the carry (v_sub_co / v_addc_co), 1.9 % slower; kept for comparison
+#endif
+#ifndef PLANES_OUT_ALIGNBIT
+#define PLANES_OUT_ALIGNBIT 1       // 0: outgoing sign by left shift and and-or, 1.4 % slower; kept for comparison
+#endif
 #ifndef PLANES_VB
 #define PLANES_VB 2                 // columns per batch of the variable pass (measured: 2 < 4 < 1 < 8)
 #endif
@@ -259,9 +265,18 @@ planes_check_pass(unsigned char *smem, const uint32_t (&radr)[CPT * 4], int D, i
                 // |v| < min1 (non-negative floats order like their bit patterns).  Two full-rate
                 // instructions where a compare and a select are two half-rate ones; the edge itself is
                 // read off the lowest set bit after the loop.
+#if PLANES_ARGMIN_FSUB
+                // the same bit from the float difference: new minimum - old minimum is negative exactly when
+                // the edge lowered it (x - x = +0; distinct floats never subtract to zero), and the
+                // subtraction is in the instruction class that issues twice as fast as the carry forms
+                float dlt;
+                asm("v_sub_f32 %0, %1, %2" : "=v"(dlt) : "v"(n1), "v"(min1));
+                LT = __builtin_amdgcn_alignbit(LT, __float_as_uint(dlt), 31);
+#else
                 uint32_t borrow_tmp;
                 asm("v_sub_co_u32 %1, vcc, %2, %3\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
                     : "+v"(LT), "=&v"(borrow_tmp) : "v"(n1), "v"(min1) : "vcc");
+#endif
                 min2 = n2;
                 min1 = n1;
             }
@@ -305,11 +320,24 @@ planes_check_pass(unsigned char *smem, const uint32_t (&radr)[CPT * 4], int D, i
     const uint32_t ej = (HEAVY ? idx & (uint32_t)(NS - 1) : idx) >> 1, ek = idx & 1u;
     const int esh = *reinterpret_cast<const int *>(smem + G::SHTAB_OFF + ((B * G::NB + ej) * 2 + ek) * 4);
     // every edge gets +-min1 ...
+#if PLANES_OUT_ALIGNBIT
+    // Sign and magnitude joined by one funnel shift: { T >> (31 - s), 2 * min1 } >> 1 has the edge's bit of T on
+    // top of the 31 magnitude bits.  A right shift issues twice as fast as the left shift and the and-or
+    // it replaces, and the funnel shift stands for the second of them.
+    const uint32_t m1x = m1 << 1;          // min1 >= 0: nothing is shifted out
+#endif
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         {
+#if PLANES_OUT_ALIGNBIT
+            const uint32_t ts = s == 31 ? T : T >> (31 - s);
+            uint32_t o;
+            asm("v_alignbit_b32 %0, %1, %2, 1" : "=v"(o) : "v"(ts), "v"(m1x));
+            lds_put_u32(smem, radr[s] + 4u * (1 + 2 * B + (s & 1)), o);
+#else
             const uint32_t rank = (uint32_t)s;
             lds_put_u32(smem, radr[s] + 4u * (1 + 2 * B + (s & 1)), m1 | ((T << rank) & 0x80000000u));
+#endif
         }
         if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
