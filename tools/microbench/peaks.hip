@@ -11,7 +11,8 @@
 constexpr int THREADS = 1024;       // 16 waves per CU, as in the decode kernels
 constexpr int ITERS = 2048;
 
-// MODE 0: ds_read_b32, 1: ds_read2_b32 (two dwords 16 bytes apart), 2: ds_read_b64, 3: ds_read_b128, 4: ds_write_b32
+// MODE 0: ds_read_b32, 1: ds_read2_b32 (two dwords 16 bytes apart), 2: ds_read_b64, 3: ds_read_b128, 4: ds_write_b32,
+// 5: ds_write_b64, 6: ds_write_b128, 7: ds_write2_b32 (two dwords 4 bytes apart)
 // stride: bytes between consecutive lanes (20 = the message-plane record, 4/8/16 = dense)
 template <int MODE>
 __global__ void __launch_bounds__(THREADS) lds_kernel(float *out, int stride, unsigned long long *cycles)
@@ -24,11 +25,15 @@ __global__ void __launch_bounds__(THREADS) lds_kernel(float *out, int stride, un
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
         uint32_t a = ((uint32_t)threadIdx.x * (uint32_t)stride + (uint32_t)u * 20480u) % 131072u;
-        if (MODE == 2) a &= ~7u;
-        if (MODE == 3) a &= ~15u;
+        if (MODE == 2 || MODE == 5) a &= ~7u;
+        if (MODE == 3 || MODE == 6) a &= ~15u;
         ad[u] = a + (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) unsigned char *)smem;
     }
     float acc = 0.0f;
+    typedef float v2f_ __attribute__((ext_vector_type(2)));
+    typedef float v4f_ __attribute__((ext_vector_type(4)));
+    v2f_ w2 = {1.0f, 2.0f};
+    v4f_ w4 = {1.0f, 2.0f, 3.0f, 4.0f};
     const unsigned long long t0 = clock64();
 #pragma unroll 1
     for (int it = 0; it < ITERS; it += 8) {
@@ -40,9 +45,12 @@ __global__ void __launch_bounds__(THREADS) lds_kernel(float *out, int stride, un
             if (MODE == 2) asm volatile("ds_read_b64 %0, %1" : "=v"(*reinterpret_cast<float2 *>(v[u])) : "v"(ad[u]));
             if (MODE == 3) asm volatile("ds_read_b128 %0, %1" : "=v"(*reinterpret_cast<float4 *>(v[u])) : "v"(ad[u]));
             if (MODE == 4) asm volatile("ds_write_b32 %0, %1" : : "v"(ad[u]), "v"(acc) : "memory");
+            if (MODE == 5) asm volatile("ds_write_b64 %0, %1" : : "v"(ad[u]), "v"(w2) : "memory");
+            if (MODE == 6) asm volatile("ds_write_b128 %0, %1" : : "v"(ad[u]), "v"(w4) : "memory");
+            if (MODE == 7) asm volatile("ds_write2_b32 %0, %1, %2 offset0:0 offset1:1" : : "v"(ad[u]), "v"(acc), "v"(acc) : "memory");
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (MODE != 4) {
+        if (MODE < 4) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 float x = v[u][0];
@@ -199,7 +207,9 @@ int main()
     struct Case { int mode; int stride; const char *name; int bytes; } cases[] = {
         {0, 4, "ds_read_b32 dense", 4}, {0, 20, "ds_read_b32 stride 20", 4}, {1, 20, "ds_read2_b32 stride 20", 8},
         {2, 8, "ds_read_b64 dense", 8}, {2, 24, "ds_read_b64 stride 24", 8}, {3, 16, "ds_read_b128 dense", 16},
-        {3, 32, "ds_read_b128 stride 32", 16}, {4, 4, "ds_write_b32 dense", 4}, {4, 20, "ds_write_b32 stride 20", 4}};
+        {3, 32, "ds_read_b128 stride 32", 16}, {4, 4, "ds_write_b32 dense", 4}, {4, 20, "ds_write_b32 stride 20", 4},
+        {5, 8, "ds_write_b64 dense", 8}, {6, 16, "ds_write_b128 dense", 16}, {7, 20, "ds_write2_b32 stride 20", 8},
+        {0, 16, "ds_read_b32 stride 16", 4}, {4, 16, "ds_write_b32 stride 16", 4}};
     bool first = true;
     for (const Case &c : cases) {
         for (int rep = 0; rep < 2; ++rep) {
@@ -208,7 +218,10 @@ int main()
             case 1: hipLaunchKernelGGL(lds_kernel<1>, dim3(cus), dim3(THREADS), lds, 0, out, c.stride, cyc); break;
             case 2: hipLaunchKernelGGL(lds_kernel<2>, dim3(cus), dim3(THREADS), lds, 0, out, c.stride, cyc); break;
             case 3: hipLaunchKernelGGL(lds_kernel<3>, dim3(cus), dim3(THREADS), lds, 0, out, c.stride, cyc); break;
-            default: hipLaunchKernelGGL(lds_kernel<4>, dim3(cus), dim3(THREADS), lds, 0, out, c.stride, cyc); break;
+            case 4: hipLaunchKernelGGL(lds_kernel<4>, dim3(cus), dim3(THREADS), lds, 0, out, c.stride, cyc); break;
+            case 5: hipLaunchKernelGGL(lds_kernel<5>, dim3(cus), dim3(THREADS), lds, 0, out, c.stride, cyc); break;
+            case 6: hipLaunchKernelGGL(lds_kernel<6>, dim3(cus), dim3(THREADS), lds, 0, out, c.stride, cyc); break;
+            default: hipLaunchKernelGGL(lds_kernel<7>, dim3(cus), dim3(THREADS), lds, 0, out, c.stride, cyc); break;
             }
             CHECK(hipDeviceSynchronize());
         }
