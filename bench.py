@@ -128,15 +128,16 @@ def lds_roofline(eng, step, F, mean_iters, k_ms, dev):
            'lds_bytes_per_frame': total, 'check_passes_per_frame': n_full, 'syndrome_only_passes_per_frame': n_synd,
            'variable_passes_per_frame': mean_iters, 'measured_in_this_run': True,
            'bytes_per_pass': {'first_check': 8 * E + 8 * M, 'check': 12 * E + 8 * M, 'syndrome_only': 4 * E, 'variable': 4 * E + 4 * N}}
-    peaks = os.path.join(ROOT, 'profiles', 'r01_onchip_peaks.json')
-    if os.path.exists(peaks):
+    peaks = next((f for f in (os.path.join(ROOT, 'profiles', n) for n in ('r02_onchip_peaks.json', 'r01_onchip_peaks.json'))
+                  if os.path.exists(f)), None)
+    if peaks:
         try:
             pk = {e['access']: e['bytes_per_clk_per_cu'] for e in json.load(open(peaks))['lds']}
             rates = {'ds_read2_b32': pk['ds_read2_b32 stride 20'], 'ds_read_b32': pk['ds_read_b32 stride 20'],
                      'ds_write_b32': pk['ds_write_b32 stride 20']}
             clk = sum(by_instr[k] / rates[k] for k in by_instr)          # LDS clocks per frame on one CU at the measured rates
             floor_s = clk * F / 256 / 2.4e9
-            out['measured_mix'] = {'rates_bytes_per_clk_per_cu': rates, 'source': 'profiles/r01_onchip_peaks.json',
+            out['measured_mix'] = {'rates_bytes_per_clk_per_cu': rates, 'source': 'profiles/' + os.path.basename(peaks),
                                    'lds_time_floor_ms': floor_s * 1e3, 'frac': floor_s / t,
                                    'bytes_by_instruction_per_frame': by_instr}
         except Exception:
