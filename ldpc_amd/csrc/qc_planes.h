@@ -376,7 +376,8 @@ __device__ __forceinline__ float planes_phi(float x)
 
 // Sum-product check pass (the rule stated with csr_spa_kernel): same structure as the min-sum
 // pass; the message slot of an edge holds F_e = phi|v_e| between the two halves.
-template <int Z, int CPT, int B, bool FIRST>
+// HOLES: some edge of the row may be missing (its record is the dummy, |v| = inf): such an edge adds no term.
+template <int Z, int CPT, int B, bool FIRST, bool HOLES>
 __device__ __forceinline__ unsigned long long
 planes_check_pass_spa(unsigned char *smem, const uint32_t (&radr)[CPT * 4], int D, int sign_mode,
                       unsigned long long synd0)
@@ -384,7 +385,7 @@ planes_check_pass_spa(unsigned char *smem, const uint32_t (&radr)[CPT * 4], int 
     typedef PlanesGeom<Z, CPT> G;
     enum { NS = G::NS, CH = 4, NCH = NS / CH };
     float F1 = 0.0f, rest = 0.0f;          // F > 0 always, so the first edge displaces the initial 0 (rest += 0)
-    uint32_t idx = 0, R = 0;
+    uint32_t GT = 0, R = 0;
     unsigned long long synd = synd0;     // set for every row if rows have an odd number of missing edges (each reads as hard decision 1)
     float p[2][CH], c[2][CH];
 #pragma unroll
@@ -414,17 +415,25 @@ planes_check_pass_spa(unsigned char *smem, const uint32_t (&radr)[CPT * 4], int 
                 R = __builtin_amdgcn_alignbit(R, __float_as_uint(v), 31);
                 const float av = fabsf(v);
                 float F = planes_phi(__builtin_amdgcn_fmed3f(av, 1e-12f, 80.0f));
-                F = av == __uint_as_float(0x7f800000u) ? 0.0f : F;          // edge of a zeroed circulant: no term
+                if (HOLES) F = av == __uint_as_float(0x7f800000u) ? 0.0f : F;       // edge of a zeroed circulant: no term
                 lds_put_f32(smem, radr[s] + 4u * (1 + 2 * B + (s & 1)), F);
-                const bool gt = F > F1;
-                rest = rest + (gt ? F1 : F);
-                idx = gt ? (uint32_t)s : idx;
-                F1 = gt ? F : F1;
+                // largest term so far and the sum of the others: the smaller of { F1, F } joins the sum, the larger
+                // stays apart; the edge that holds it is the last one that raised it strictly (one bit per edge,
+                // the sign of old maximum - new maximum, first edge highest)
+                float hi, lo, dgt;
+                asm("v_max_f32 %0, %1, %2" : "=v"(hi) : "v"(F1), "v"(F));
+                asm("v_min_f32 %0, %1, %2" : "=v"(lo) : "v"(F1), "v"(F));
+                asm("v_sub_f32 %0, %1, %2" : "=v"(dgt) : "v"(F1), "v"(hi));
+                GT = __builtin_amdgcn_alignbit(GT, __float_as_uint(dgt), 31);
+                rest = rest + lo;
+                F1 = hi;
             }
         }
-        asm volatile("" : "+v"(F1), "+v"(rest), "+v"(idx), "+v"(R), "+s"(synd));
+        asm volatile("" : "+v"(F1), "+v"(rest), "+v"(GT), "+v"(R), "+s"(synd));
         __builtin_amdgcn_sched_barrier(0);
     }
+    if (NS < 32) GT <<= (32 - NS);
+    const uint32_t idx = GT != 0u ? 31u - (uint32_t)__builtin_ctz(GT) : 0u;
     if (NS < 32) R <<= (32 - NS);
     uint32_t S = __popc(R) & 1u;
     if (sign_mode == LDPC_SIGN_CORRECTED) S ^= (uint32_t)D & 1u;       // D: the row's real degree
@@ -799,7 +808,8 @@ planes_role(unsigned char *smem, const PlanesTables &tb, const DecodeArgs &a)
         {
             if (live) {
                 const unsigned long long synd = SPA
-                    ? planes_check_pass_spa<Z, CPT, B, true>(smem, radr, D, a.sign_mode, synd0)
+                    ? (D == NS ? planes_check_pass_spa<Z, CPT, B, true, false>(smem, radr, D, a.sign_mode, synd0)
+                               : planes_check_pass_spa<Z, CPT, B, true, true>(smem, radr, D, a.sign_mode, synd0))
                     : planes_check_pass<Z, CPT, B, true, HV>(smem, radr, D, a.sign_mode, ic, synd0, a.ms_alpha, a.ms_beta, xs);
                 // flags[parity]: number of rows whose check fails (bit 20: raised by the syndrome-only pass)
                 if (synd != 0ull && lane == 0) atomicAdd(&flags[0], (int)__popcll(synd));
@@ -854,7 +864,8 @@ planes_role(unsigned char *smem, const PlanesTables &tb, const DecodeArgs &a)
                     }
                     if (live) {
                         const unsigned long long synd = SPA
-                            ? planes_check_pass_spa<Z, CPT, B, false>(smem, radr, D, a.sign_mode, synd0)
+                            ? (D == NS ? planes_check_pass_spa<Z, CPT, B, false, false>(smem, radr, D, a.sign_mode, synd0)
+                                       : planes_check_pass_spa<Z, CPT, B, false, true>(smem, radr, D, a.sign_mode, synd0))
                             : planes_check_pass<Z, CPT, B, false, HV>(smem, radr, D, a.sign_mode, ic, synd0, a.ms_alpha, a.ms_beta, xs);
                         if (synd != 0ull && lane == 0) atomicAdd(&flags[par], (int)__popcll(synd));
                     }
