@@ -77,6 +77,9 @@ planes_load_frame(const void *llr, int is_f64, int64_t frame_base, uint32_t firs
 #ifndef PLANES_OUT_ALIGNBIT
 #define PLANES_OUT_ALIGNBIT 1       // 0: outgoing sign by left shift and and-or, 1.4 % slower; kept for comparison
 #endif
+#ifndef PLANES_CANON
+#define PLANES_CANON 1              // zeros are kept as -0 in LDS (posteriors and messages), so that a posterior's sign bit is its hard decision; 0: compare per edge, 0.95 % slower, kept for comparison
+#endif
 #ifndef PLANES_VB
 #define PLANES_VB 2                 // columns per batch of the variable pass (measured: 2 < 4 < 1 < 8)
 #endif
@@ -160,13 +163,28 @@ struct PlanesGeom {
 // last check pass finds every parity satisfied and all its other work is thrown away; when the pass
 // before left no more than PLANES_PRECHECK_T rows unsatisfied, this much cheaper pass is run first
 // and the full one only if it still finds a failing row.  Same stop decision, same iteration count.
-template <int Z, int CPT, int HV>
+template <int Z, int CPT, int HV, bool CANON = false>
 __device__ __forceinline__ unsigned long long
 planes_syndrome_only(const unsigned char *smem, const uint32_t (&radr)[CPT * 4], unsigned long long synd0,
                      const PlanesXState &xs)
 {
     enum { NS = CPT * 4, CHS = 8, HEAVY = HV > 0, MX = PlanesHeavy<HV>::MX };
     unsigned long long synd = synd0;
+    if (CANON) {
+        // a stored posterior is never +0 (a zero is kept as -0): sign bit clear <=> hard decision 1, and over an
+        // even number of slots the XOR of the sign bits is the XOR of the hard decisions
+        static_assert(!CANON || NS % 2 == 0, "even number of slots");
+        uint32_t H = 0;
+#pragma unroll
+        for (int s0 = 0; s0 < NS; s0 += CHS) {
+            float p[CHS];
+#pragma unroll
+            for (int u = 0; u < CHS; ++u) p[u] = lds_f32(smem, radr[s0 + u]);
+#pragma unroll
+            for (int u = 0; u < CHS; ++u) H ^= __float_as_uint(p[u]);
+        }
+        return synd ^ __ballot((int)H < 0);
+    }
     if (HEAVY) {
 #pragma unroll
         for (int x = 0; x < MX; ++x)
@@ -186,7 +204,7 @@ planes_syndrome_only(const unsigned char *smem, const uint32_t (&radr)[CPT * 4],
 // Check pass of one row of block-row B.  FIRST: the row's previous messages are all +0
 // (fresh decoder, checkNode.__init__ ldpc.py:121) and are not read.  Returns the lanes
 // whose parity check on the current hard decisions fails.
-template <int Z, int CPT, int B, bool FIRST, int HV>
+template <int Z, int CPT, int B, bool FIRST, int HV, bool CANON = false>
 __device__ __forceinline__ unsigned long long
 planes_check_pass(unsigned char *smem, const uint32_t (&radr)[CPT * 4], int D, int sign_mode, int ic,
                   unsigned long long synd0, float alpha, float beta, PlanesXState &xs)
@@ -199,6 +217,13 @@ planes_check_pass(unsigned char *smem, const uint32_t (&radr)[CPT * 4], int D, i
     unsigned long long synd = synd0;     // set for every row if rows have an odd number of missing edges (each reads as hard decision 1)
     uint32_t RX = 0;                     // bit x: v < 0 on extra edge x
     uint32_t LT = 0;                     // one bit per slot edge: it lowered the running minimum
+    // CANON: posteriors and messages are stored with -0 in place of either zero.  A posterior's sign bit is then
+    // clear exactly when its hard decision is 1, so the row parity is the top bit of the XOR of the words it
+    // reads (one instruction of the fast class per edge instead of a compare and a scalar XOR); p - c stays
+    // exact: (-0) - (-0) = +0 as (+0) - (+-0), x - (-0) = x, (-0) - x = -x.  The first pass of a frame reads
+    // channel values, which are not stored that way, and compares.
+    enum { XORP = CANON && !FIRST };
+    uint32_t H = 0;
     if (HEAVY) {
         // The extra edges first (minimum, second minimum and sign product do not depend on the order
         // edges are visited in; equal magnitudes make min2 == min1, so neither does the result of argmin).
@@ -251,7 +276,8 @@ planes_check_pass(unsigned char *smem, const uint32_t (&radr)[CPT * 4], int D, i
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
             {
-                synd ^= __ballot(p[cb][u] > 0.0f);                          // slicer, ldpc.py:47
+                if (XORP) H ^= __float_as_uint(p[cb][u]);
+                else synd ^= __ballot(p[cb][u] > 0.0f);                     // slicer, ldpc.py:47
                 const float v = FIRST ? p[cb][u] : p[cb][u] - c[cb][u];     // receive, ldpc.py:161 (x - 0 == x)
                 R = __builtin_amdgcn_alignbit(R, __float_as_uint(v), 31);   // (R << 1) | sign(v), ldpc.py:139
                 // second minimum and minimum as bare instructions: behind the register pins below the
@@ -285,11 +311,13 @@ planes_check_pass(unsigned char *smem, const uint32_t (&radr)[CPT * 4], int D, i
             // |v|, every intermediate minimum and every compare mask alive until then
             // (60+ vector and 60+ scalar registers, spills).
             if ((u & 3) == 3) {
-                asm volatile("" : "+v"(min1), "+v"(min2), "+v"(LT), "+v"(R), "+s"(synd));
+                if (XORP) asm volatile("" : "+v"(min1), "+v"(min2), "+v"(LT), "+v"(R), "+v"(H));
+                else asm volatile("" : "+v"(min1), "+v"(min2), "+v"(LT), "+v"(R), "+s"(synd));
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
+    if (XORP) synd ^= __ballot((int)H < 0);
     // the last slot edge that lowered the minimum is the arg-min (bit NS-1-s of LT belongs to edge s),
     // unless no slot edge went below what the extra edges left
     if (LT != 0u) idx = (uint32_t)(NS - 1) - (uint32_t)__builtin_ctz(LT);
@@ -300,12 +328,14 @@ planes_check_pass(unsigned char *smem, const uint32_t (&radr)[CPT * 4], int D, i
     if (HEAVY) S ^= __popc(RX) & 1u;
     if (sign_mode == LDPC_SIGN_CORRECTED) S ^= (uint32_t)D & 1u;       // D: the row's real degree
     const uint32_t full = 0xffffffffu << (32 - NS);
-    const uint32_t T = R ^ (S ? full : 0u);
+    uint32_t T = R ^ (S ? full : 0u);
     if (alpha != 1.0f || beta != 0.0f) {                    // normalised / offset min-sum (uniform branch)
         min1 = ms_correct(min1, alpha, beta);
         min2 = ms_correct(min2, alpha, beta);
     }
     const uint32_t m1 = __float_as_uint(min1), m2 = __float_as_uint(min2);
+    const uint32_t T0 = T;                                  // the signs as they are, for the arg-min edge
+    if (CANON) T |= m1 == 0u ? full : 0u;                   // a zero message is stored as -0
     if (HEAVY) {
         // extra edges: +-min1, or +-min2 on the arg-min edge (ldpc.py:190-191), to the scratch row
         const uint32_t SX = RX ^ (S ? 0xffffffffu : 0u);
@@ -348,7 +378,7 @@ planes_check_pass(unsigned char *smem, const uint32_t (&radr)[CPT * 4], int D, i
         const uint32_t adr = (uint32_t)(ej * Z + ci) * G::CB + 4u * (1 + 2 * B) + 4u * ek;
         const uint32_t rank = idx & 31u;
         if (D > 0 && (!HEAVY || idx < (uint32_t)NS))          // D == 0: every edge is a dummy; HEAVY: the arg-min may be an extra edge
-            lds_put_u32(smem, adr, m2 | ((T << rank) & 0x80000000u));
+            lds_put_u32(smem, adr, m2 | ((T0 << rank) & 0x80000000u) | (CANON && m2 == 0u ? 0x80000000u : 0u));
     }
     return synd;
 }
@@ -480,7 +510,7 @@ template <int Z, int CPT, int B, bool SPA, bool GEN, int HV>
 __device__ __forceinline__ void
 planes_role(unsigned char *smem, const PlanesTables &tb, const DecodeArgs &a)
 {
-    enum { HEAVY = HV > 0, MX = PlanesHeavy<HV>::MX, MW = PlanesHeavy<HV>::MW };
+    enum { HEAVY = HV > 0, MX = PlanesHeavy<HV>::MX, MW = PlanesHeavy<HV>::MW, CANON = PLANES_CANON && !SPA && !HEAVY };
     static_assert(!(HEAVY && SPA), "heavy circulants: min-sum only");
     typedef PlanesGeom<Z, CPT> G;
     enum { MB = G::MB, W = G::W, NB = G::NB, NS = G::NS, N = G::N, ZP = G::ZP, CB = G::CB,
@@ -631,7 +661,15 @@ planes_role(unsigned char *smem, const PlanesTables &tb, const DecodeArgs &a)
                 const bool lo = (lomask >> q) & 1u;
                 acc = acc + (lo ? m[u][2] : m[u][3]);             // lower check index first
                 acc = acc + (lo ? m[u][3] : m[u][2]);
-                lds_put_f32(smem, adr, acc + y[q]);               // channel last, ldpc.py:322
+                float post = acc + y[q];                          // channel last, ldpc.py:322
+                if (CANON) {
+                    // -(0 - post): post itself, except that +0 becomes -0 (as bare instructions: the compiler
+                    // would fold 0 - x into a negation and the two negations away)
+                    float t;
+                    asm("v_sub_f32 %0, 0, %1" : "=v"(t) : "v"(post));
+                    post = __uint_as_float(__float_as_uint(t) ^ 0x80000000u);
+                }
+                lds_put_f32(smem, adr, post);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -810,7 +848,7 @@ planes_role(unsigned char *smem, const PlanesTables &tb, const DecodeArgs &a)
                 const unsigned long long synd = SPA
                     ? (D == NS ? planes_check_pass_spa<Z, CPT, B, true, false>(smem, radr, D, a.sign_mode, synd0)
                                : planes_check_pass_spa<Z, CPT, B, true, true>(smem, radr, D, a.sign_mode, synd0))
-                    : planes_check_pass<Z, CPT, B, true, HV>(smem, radr, D, a.sign_mode, ic, synd0, a.ms_alpha, a.ms_beta, xs);
+                    : planes_check_pass<Z, CPT, B, true, HV, CANON>(smem, radr, D, a.sign_mode, ic, synd0, a.ms_alpha, a.ms_beta, xs);
                 // flags[parity]: number of rows whose check fails (bit 20: raised by the syndrome-only pass)
                 if (synd != 0ull && lane == 0) atomicAdd(&flags[0], (int)__popcll(synd));
             }
@@ -852,7 +890,7 @@ planes_role(unsigned char *smem, const PlanesTables &tb, const DecodeArgs &a)
                     if (unsat <= precheck_t) {
                         ++n_synd;
                         if (live) {
-                            const unsigned long long synd = planes_syndrome_only<Z, CPT, HV>(smem, radr, synd0, xs);
+                            const unsigned long long synd = planes_syndrome_only<Z, CPT, HV, CANON>(smem, radr, synd0, xs);
                             if (synd != 0ull && lane == 0) flags[par] = 1 << 20;
                         }
                         lds_barrier();
@@ -866,7 +904,7 @@ planes_role(unsigned char *smem, const PlanesTables &tb, const DecodeArgs &a)
                         const unsigned long long synd = SPA
                             ? (D == NS ? planes_check_pass_spa<Z, CPT, B, false, false>(smem, radr, D, a.sign_mode, synd0)
                                        : planes_check_pass_spa<Z, CPT, B, false, true>(smem, radr, D, a.sign_mode, synd0))
-                            : planes_check_pass<Z, CPT, B, false, HV>(smem, radr, D, a.sign_mode, ic, synd0, a.ms_alpha, a.ms_beta, xs);
+                            : planes_check_pass<Z, CPT, B, false, HV, CANON>(smem, radr, D, a.sign_mode, ic, synd0, a.ms_alpha, a.ms_beta, xs);
                         if (synd != 0ull && lane == 0) atomicAdd(&flags[par], (int)__popcll(synd));
                     }
                     ++n_full;
@@ -917,7 +955,7 @@ planes_role(unsigned char *smem, const PlanesTables &tb, const DecodeArgs &a)
 #pragma unroll
                 for (int t = 0; t < STEPS; ++t) {
                     const int c = w0 + t * NT + lane;
-                    if (c < N) reinterpret_cast<float *>(a.soft)[frame * N + c] = pv[t];
+                    if (c < N) reinterpret_cast<float *>(a.soft)[frame * N + c] = CANON ? pv[t] + 0.0f : pv[t];   // (-0) + 0 = +0
                 }
             }
 #endif
