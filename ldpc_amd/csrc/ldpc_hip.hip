@@ -96,45 +96,8 @@ struct CsrTables {
     const int32_t *col_e;    // [E] edge number of that entry inside its row
 };
 
-enum { GEN_MAX_POINTS = 8, GEN_MAX_BATCH = 8192 };   // sweep points, and frames in all, that one launch may serve
-
-struct DecodeArgs {
-    const void *llr;       // [frames][n] float32, or float64 if llr_f64
-    int llr_f64;
-    float llr_scale;
-    int64_t n_frames;
-    int max_iters;
-    int sign_mode;
-    uint8_t *hard;         // [frames][ceil(n/8)] or null
-    int32_t *iters;        // [frames] or null
-    uint8_t *conv;         // [frames] or null
-    int32_t *ones;         // [frames] or null
-    void *soft;            // [frames][n] T or null
-    unsigned char *chain;  // null, or the persistent check-node state of a chained decoder:
-                           // frames are decoded one after another (grid of 1 workgroup) and the
-                           // check rows' last outgoing messages carry over from frame to frame
-    float ms_alpha, ms_beta;   // min-sum magnitude correction: |c2v| = max(alpha*min - beta, 0); 1, 0 = the reference's plain rule
-    int precheck;          // rows left unsatisfied up to which an iteration starts with a syndrome-only pass;
-                           // -1 = each kernel's own default, 0 = never (LDPC_HIP_PRECHECK_T)
-    int *work;             // null, or a zeroed counter: workgroups claim frames gridDim.x + atomicAdd(work, 1)
-                           // one at a time instead of walking a fixed stride (message-plane kernel)
-    // Kernels that make their own channel values (the GEN instantiations; llr is then unused):
-    // frame f of the launch is frame gen_first_frame + f of noise stream (gen_seed, gen_stream),
-    // y = -1 + gen_sigma * z (awgn.h), and the per-frame channel statistics go to
-    unsigned long long gen_seed = 0, gen_first_frame = 0;
-    uint32_t gen_stream = 0;
-    float gen_sigma = 0.0f;
-    // Several noise streams in one launch (a small sweep: the points' frames decode side by side instead of
-    // one launch after the other).  gen_per_point > 0: frame f of the launch belongs to point p = f / gen_per_point
-    // and is frame gen_first_frame + f % gen_per_point of stream gen_stream + p, made with gen_point_sigma[p]
-    // and scaled by gen_point_scale[p] (gen_sigma and llr_scale are then unused).
-    uint32_t gen_per_point = 0;
-    float gen_point_sigma[GEN_MAX_POINTS] = {}, gen_point_scale[GEN_MAX_POINTS] = {};
-    int32_t *gen_uncoded = nullptr;              // [frames] channel hard-decision errors, or null
-    unsigned long long *gen_sumsq = nullptr;     // [frames] sum of z^2 in 2^-19 fixed point (awgn.h), or null
-    // null, or [2] summed over the launch: full check passes, syndrome-only passes (measurement only)
-    unsigned long long *pass_counts = nullptr;
-};
+#include "decode_args.h"
+#include "qc_heavy.h"
 
 // ---------------------------------------------------------------- small helpers
 template <typename T> struct Vec2;
@@ -1186,6 +1149,7 @@ struct Launch {
     bool packed = false;      // ... the one with records of the columns' own length (edge_packed.h)
     bool planes = false;      // message-plane kernel (qc_planes.h)
     bool csr = false;         // csr_minsum_kernel (state in a global workspace)
+    bool heavyqc = false;     // qc_heavy_kernel (qc_heavy.hip)
     int max_grid = 1;         // workgroups that are resident at once
     size_t ws_stride = 0;     // bytes of global workspace per workgroup (0: none)
 };
@@ -1213,6 +1177,10 @@ struct ldpc_handle {
     bool planes_heavy = false;     // some circulant has weight > 2 (extra edges through a global scratch row)
     int planes_max_w = 0;          // largest circulant weight
     PlanesTables planes{};
+    // heavy-circulant kernel (float32 min-sum; qc_heavy.h)
+    bool heavyqc_ok = false;
+    HeavyTables heavyqc{};
+    size_t heavyqc_lds = 0;
     // CSR
     CsrTables csr{};
     const int32_t *edge_slot = nullptr;   // [E] rank of each edge's row inside its column
@@ -1655,6 +1623,65 @@ extern "C" int ldpc_create_qc(int device, int Z, int mb, int nb, const int32_t *
             h->planes_max_w = h_max_w;
         }
     }
+    // heavy-circulant kernel (qc_heavy.h): float32 min-sum on what the message-plane and the regular kernels
+    // do not take -- checks of up to 128 edges, circulants of weight <= HQ_WMAX
+    {
+        const char *force = hook("LDPC_HIP_FORCE_HEAVYQC"), *off = hook("LDPC_HIP_NO_HEAVYQC");
+        const bool forced = force && force[0] == '1';
+        int max_w = 0, min_deg = max_deg;
+        for (int b = 0; b < mb; ++b) {
+            min_deg = std::min(min_deg, blk_ptr[(b + 1) * nb] - blk_ptr[b * nb]);
+            for (int j = 0; j < nb; ++j) max_w = std::max(max_w, blk_ptr[b * nb + j + 1] - blk_ptr[b * nb + j]);
+        }
+        const int dpad_max = (max_deg + HQ_CH - 1) / HQ_CH * HQ_CH;
+        const int nwu = (dpad_max + 31) / 32;
+        const HeavyGeom geo(Z, Zp, mb, nb, nwu);
+        // one frame per workgroup: worth it where the table-driven kernel holds one frame per workgroup too
+        const bool wanted = forced || (!h->planes_ok && !h->is_regular && mb * Zp > 512);
+        if (wanted && !(off && off[0] == '1') && mb <= HQ_MAXMB && h->cols_per_thread <= HQ_CPT && max_w <= HQ_WMAX &&
+            min_deg >= 2 && max_deg <= 32 * HQ_NW && Z <= 1023 && (size_t)geo.bytes <= h->lds_max) {
+            HeavyTables &t = h->heavyqc;
+            t.Z = Z; t.Zp = Zp; t.mb = mb; t.nb = nb; t.n = h->n; t.nwu = nwu;
+            std::vector<uint32_t> rowtab((size_t)mb * geo.tabw, geo.dummy_off);
+            for (int b = 0; b < mb; ++b) {
+                t.deg[b] = row_ptr[b + 1] - row_ptr[b];
+                t.dpad[b] = (t.deg[b] + HQ_CH - 1) / HQ_CH * HQ_CH;
+                for (int e = 0; e < t.deg[b]; ++e) {
+                    const int2 en = row_ent[(size_t)row_ptr[b] + e];           // { j * Z, s }
+                    rowtab[(size_t)b * geo.tabw + e] = (uint32_t)((en.x / Z) * (int)geo.Z2 + en.y) * 4u;
+                }
+            }
+            const size_t gstride = (size_t)(HQ_CPT * mb + 1) * HQ_BLK;      // words per thread group: its blocks and a spare one
+            std::vector<uint32_t> coltab((size_t)mb * gstride, 0u);            // (uploads start on 256-byte boundaries)
+            for (int g = 0; g < mb; ++g) {
+                t.ncol[g] = 0;
+                for (int q = 0; q < HQ_CPT; ++q) {
+                    const int j = g + q * mb;
+                    if (j >= nb) continue;
+                    t.ncol[g] = q + 1;
+                    for (int b = 0; b < mb; ++b) {
+                        const int k0 = blk_ptr[b * nb + j], k1 = blk_ptr[b * nb + j + 1];
+                        std::vector<int2> ent;
+                        for (int k = k0; k < k1; ++k) ent.push_back(make_int2(shifts[k], edge_no[k]));
+                        std::sort(ent.begin(), ent.end(), [](const int2 &x, const int2 &y) { return x.x > y.x; });
+                        uint32_t *blk = &coltab[(size_t)g * gstride + ((size_t)q * mb + b) * HQ_BLK];
+                        blk[0] = (uint32_t)ent.size() << 25;
+                        for (size_t k = 0; k < ent.size(); ++k) {
+                            const uint32_t s = (uint32_t)ent[k].x, e = (uint32_t)ent[k].y, wd = e >> 5;
+                            const uint32_t row = (uint32_t)b * geo.Z2 + (uint32_t)Z - s;
+                            const uint32_t rec = geo.rec_off + (geo.split ? 0u : wd * geo.rec_wstride) + row * 16u;
+                            const uint32_t swa = geo.split ? geo.sw_off + wd * geo.sw_wstride + row * 4u : 0u;
+                            blk[2 * k] |= rec | (e << 18);
+                            blk[2 * k + 1] = swa | (s << 18);
+                        }
+                    }
+                }
+            }
+            if ((rc = upload(h, rowtab, &t.rowtab)) || (rc = upload(h, coltab, &t.coltab))) { ldpc_destroy(h); return rc; }
+            h->heavyqc_ok = true;
+            h->heavyqc_lds = geo.bytes;
+        }
+    }
     // column and row degrees, which kernel selection looks at
     h->max_col_deg = 0;
     for (int j = 0; j < nb; ++j) {
@@ -1667,7 +1694,7 @@ extern "C" int ldpc_create_qc(int device, int Z, int mb, int nb, const int32_t *
     // the same graph as an edge list: now, unless the message-plane kernels take the code (then on first need)
     {
         const char *eager = hook("LDPC_HIP_EAGER_EDGES");
-        if (h->planes_ok && !(eager && eager[0] == '1')) {
+        if ((h->planes_ok || h->heavyqc_ok) && !(eager && eager[0] == '1')) {
             h->qc_blk_ptr.assign(blk_ptr, blk_ptr + nblk + 1);
             h->qc_shifts.assign(shifts, shifts + blk_ptr[nblk]);
         } else if ((rc = stage_qc_edges(h, blk_ptr, shifts))) {
@@ -2044,7 +2071,11 @@ static int select_kernel(ldpc_handle *h, int algo, int prec, bool chained, Launc
         L->ws_stride = L->spa_lds ? 0 : ((spa_state_bytes(h, prec) + 255) & ~(size_t)255);
         return 0;
     }
-    if (!(h->is_qc && planes_applies(h, prec, chained)) && packed_applies(h, prec, chained)) {
+    // LDPC_HIP_FORCE_HEAVYQC=1 (test hook): the heavy-circulant kernel wherever its tables were built
+    const char *force_hq = hook("LDPC_HIP_FORCE_HEAVYQC");
+    const bool heavy_ok = h->is_qc && h->heavyqc_ok && prec == 32 && !chained;
+    const bool heavy_first = heavy_ok && force_hq && force_hq[0] == '1';
+    if (!heavy_first && !(h->is_qc && planes_applies(h, prec, chained)) && packed_applies(h, prec, chained)) {
         const PackedPlan pl = packed_plan(h);
         L->fn = pl.fn; L->fpw = pl.F; L->block = pl.block; L->lds = pl.lds;
         L->slots = true; L->packed = true;
@@ -2053,7 +2084,7 @@ static int select_kernel(ldpc_handle *h, int algo, int prec, bool chained, Launc
         L->max_grid = h->n_cu * per_cu;
         return 0;
     }
-    if (!(h->is_qc && planes_applies(h, prec, chained)) && slots_applies(h, prec, chained)) {
+    if (!heavy_first && !(h->is_qc && planes_applies(h, prec, chained)) && slots_applies(h, prec, chained)) {
         int rc = slots_pick(h, false, L);
         if (rc) return rc;
         if ((rc = blocks_per_cu(h->device, L->fn, L->block, L->lds, &per_cu, true))) return rc;
@@ -2063,13 +2094,20 @@ static int select_kernel(ldpc_handle *h, int algo, int prec, bool chained, Launc
     if (h->is_qc) {
         const int sb = h->max_row_deg > 64 ? 128 : h->max_row_deg > 32 ? 64 : 32;
         int rc;
-        if (planes_applies(h, prec, chained)) rc = planes_pick(h, false, L);
+        auto heavy_pick = [&]() {
+            L->fn = heavyqc_kernel(h->heavyqc.nwu);
+            L->block = h->qc.mb * h->qc.Zp; L->fpw = 1; L->lds = h->heavyqc_lds; L->heavyqc = true;
+            return 0;
+        };
+        if (heavy_first) rc = heavy_pick();
+        else if (planes_applies(h, prec, chained)) rc = planes_pick(h, false, L);
         else if (h->is_regular) rc = prec == 32 ? reg_select<float>(h, chained, L) : reg_select<double>(h, chained, L);
+        else if (heavy_ok) rc = heavy_pick();
         else if (prec == 32) rc = sb == 128 ? qc_select<float, 128>(h, chained, L) : sb == 64 ? qc_select<float, 64>(h, chained, L) : qc_select<float, 32>(h, chained, L);
         else            rc = sb == 128 ? qc_select<double, 128>(h, chained, L) : sb == 64 ? qc_select<double, 64>(h, chained, L) : qc_select<double, 32>(h, chained, L);
         if (rc) return rc;
         if (L->lds <= h->lds_max) {
-            if ((rc = blocks_per_cu(h->device, L->fn, L->block, L->lds, &per_cu, L->planes))) return rc;
+            if ((rc = blocks_per_cu(h->device, L->fn, L->block, L->lds, &per_cu, L->planes || L->heavyqc))) return rc;
             if (L->fn_gen && (rc = blocks_per_cu(h->device, L->fn_gen, L->block, L->lds, &per_cu, L->planes))) return rc;
             L->max_grid = h->n_cu * per_cu;
             return 0;
@@ -2207,6 +2245,9 @@ static int launch_decode(ldpc_handle *h, int algo, int prec, const DecodeArgs &a
         if (args.chain) ws = args.chain;
         void *kargs[] = {&tb, &a, &ws, &stride};
         HIP_TRY(hipLaunchKernel(L.fn, dim3(L.grid), dim3(L.block), kargs, 0, h->stream));
+    } else if (L.heavyqc) {
+        if ((rc = claim_counter(h, L, &a, fixed))) return rc;
+        HIP_TRY((hipError_t)heavyqc_launch(L.fn, h->heavyqc, a, L.grid, L.block, L.lds, h->stream));
     } else if (h->is_regular) {
         RegTables tb = h->reg;
         if (!a.chain && (rc = claim_counter(h, L, &a, fixed))) return rc;      // a re-used decoder takes its frames in order
