@@ -1633,7 +1633,7 @@ extern "C" int ldpc_create_qc(int device, int Z, int mb, int nb, const int32_t *
             min_deg = std::min(min_deg, blk_ptr[(b + 1) * nb] - blk_ptr[b * nb]);
             for (int j = 0; j < nb; ++j) max_w = std::max(max_w, blk_ptr[b * nb + j + 1] - blk_ptr[b * nb + j]);
         }
-        const int dpad_max = (max_deg + HQ_CH - 1) / HQ_CH * HQ_CH;
+        const int dpad_max = (max_deg + HQ_PAD - 1) / HQ_PAD * HQ_PAD;
         const int nwu = (dpad_max + 31) / 32;
         const HeavyGeom geo(Z, Zp, mb, nb, nwu);
         // one frame per workgroup: worth it where the table-driven kernel holds one frame per workgroup too
@@ -1642,16 +1642,19 @@ extern "C" int ldpc_create_qc(int device, int Z, int mb, int nb, const int32_t *
             min_deg >= 2 && max_deg <= 32 * HQ_NW && Z <= 1023 && (size_t)geo.bytes <= h->lds_max) {
             HeavyTables &t = h->heavyqc;
             t.Z = Z; t.Zp = Zp; t.mb = mb; t.nb = nb; t.n = h->n; t.nwu = nwu;
-            std::vector<uint32_t> rowtab((size_t)mb * geo.tabw, geo.dummy_off);
+            std::vector<uint32_t> rowtab((size_t)2 * mb * geo.tabw, geo.dummy_off);
+            auto table_word = [](uint32_t s, uint32_t e) { return (s << 18) | (e << 5) | (31u - (e & 31u)); };
             for (int b = 0; b < mb; ++b) {
                 t.deg[b] = row_ptr[b + 1] - row_ptr[b];
-                t.dpad[b] = (t.deg[b] + HQ_CH - 1) / HQ_CH * HQ_CH;
+                t.dpad[b] = (t.deg[b] + HQ_PAD - 1) / HQ_PAD * HQ_PAD;
                 for (int e = 0; e < t.deg[b]; ++e) {
                     const int2 en = row_ent[(size_t)row_ptr[b] + e];           // { j * Z, s }
                     rowtab[(size_t)b * geo.tabw + e] = (uint32_t)((en.x / Z) * (int)geo.Z2 + en.y) * 4u;
+                    rowtab[(size_t)(mb + b) * geo.tabw + e] = table_word((uint32_t)en.y, (uint32_t)e);
                 }
             }
-            const size_t gstride = (size_t)(HQ_CPT * mb + 1) * HQ_BLK;      // words per thread group: its blocks and a spare one
+            const size_t blkw = geo.split ? 2 * HQ_BLK : HQ_BLK;
+            const size_t gstride = (size_t)(HQ_CPT * mb + 2) * blkw;           // words per thread group: its blocks and two spare ones
             std::vector<uint32_t> coltab((size_t)mb * gstride, 0u);            // (uploads start on 256-byte boundaries)
             for (int g = 0; g < mb; ++g) {
                 t.ncol[g] = 0;
@@ -1664,15 +1667,14 @@ extern "C" int ldpc_create_qc(int device, int Z, int mb, int nb, const int32_t *
                         std::vector<int2> ent;
                         for (int k = k0; k < k1; ++k) ent.push_back(make_int2(shifts[k], edge_no[k]));
                         std::sort(ent.begin(), ent.end(), [](const int2 &x, const int2 &y) { return x.x > y.x; });
-                        uint32_t *blk = &coltab[(size_t)g * gstride + ((size_t)q * mb + b) * HQ_BLK];
-                        blk[0] = (uint32_t)ent.size() << 25;
+                        uint32_t *blk = &coltab[(size_t)g * gstride + ((size_t)q * mb + b) * blkw];
+                        blk[14] = (uint32_t)ent.size();
                         for (size_t k = 0; k < ent.size(); ++k) {
                             const uint32_t s = (uint32_t)ent[k].x, e = (uint32_t)ent[k].y, wd = e >> 5;
                             const uint32_t row = (uint32_t)b * geo.Z2 + (uint32_t)Z - s;
-                            const uint32_t rec = geo.rec_off + (geo.split ? 0u : wd * geo.rec_wstride) + row * 16u;
-                            const uint32_t swa = geo.split ? geo.sw_off + wd * geo.sw_wstride + row * 4u : 0u;
-                            blk[2 * k] |= rec | (e << 18);
-                            blk[2 * k + 1] = swa | (s << 18);
+                            blk[2 * k] = geo.rec_off + (geo.split ? 0u : wd * geo.rec_wstride) + row * 16u;
+                            blk[2 * k + 1] = table_word(s, e);
+                            if (geo.split) blk[16 + k] = geo.sw_off + wd * geo.sw_wstride + row * 4u;
                         }
                     }
                 }

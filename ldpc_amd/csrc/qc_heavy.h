@@ -12,12 +12,13 @@
 #include <hip/hip_runtime.h>
 
 enum {
-    HQ_WMAX = 8,        // largest circulant weight
+    HQ_WMAX = 7,        // largest circulant weight (what a gym action installs at most: models.py:296, 368)
     HQ_CPT = 8,         // block-columns per thread group: ceil(nb / mb) <= HQ_CPT
     HQ_MAXMB = 8,       // block-rows
     HQ_NW = 4,          // sign words of a check row: up to 128 edges
     HQ_BLK = 16,        // words of one block in the column table
-    HQ_CH = 8           // edges per step of the check pass; rows are padded to a multiple with dummy edges
+    HQ_CH = 8,          // edges per step of the check pass
+    HQ_PAD = 4          // rows are padded to a multiple of this with dummy edges (the walk can end in mid-step)
 };
 
 // LDS layout of one frame.  Everything a lane reads at "its position + a shift" is stored TWICE, at
@@ -48,24 +49,27 @@ struct HeavyGeom {
         flag_off = sw_off + (split ? nwu * sw_wstride : 0);
         rowtab_off = flag_off + 16;                 // [mb][tabw] words: the check pass's edge table, as long as the
         tabw = 32 * (nwu <= 2 ? 2 : 4);             // kernel variant's unrolled walk (which reads ahead of the row's end)
-        bytes = rowtab_off + mb * tabw * 4;
+        bytes = rowtab_off + 2 * mb * tabw * 4;     // ... followed by [mb][tabw] words: the edges' column-table words
     }
 };
 
 struct HeavyTables {
     int Z, Zp, mb, nb, n, nwu;
     int deg[HQ_MAXMB];          // edges of a row of block-row b
-    int dpad[HQ_MAXMB];         // ... padded to a multiple of HQ_CH
+    int dpad[HQ_MAXMB];         // ... padded to a multiple of HQ_PAD
     int ncol[HQ_MAXMB];         // block-columns thread group g owns: j = g + q mb < nb, q < ncol[g]
-    // [mb][HeavyGeom::tabw]: byte address of the posterior that lane 0 of block-row b reads along edge e
-    // (lane i adds 4 i); padding edges point to the dummy row.  Copied into LDS at launch.
+    // [2][mb][HeavyGeom::tabw], copied into LDS at launch.  First half: byte address of the posterior that
+    // lane 0 of block-row b reads along edge e (lane i adds 4 i); padding edges point to the dummy row.
+    // Second half: the edge's word in the column table (below), which a row stores for its arg-min edge.
     const uint32_t *rowtab;
-    // [mb][HQ_CPT * mb + 1] blocks of 16 words (64 bytes; read with one scalar load each, the next block's
-    // while this one is summed), for thread group g its t-th block, t = q mb + b: block (b, g + q mb).
-    // Two words per shift s, shifts descending:
-    //   word 2k     byte address of the record of row (Z - s) of block-row b, in the copy that belongs to the
-    //               edge's sign word (lane c adds 16 c)  |  edge number in the row's list << 18  |  (k = 0:) weight << 25
-    //   word 2k + 1 split layout: byte address of the sign word of that row (lane c adds 4 c)  |  s << 18
+    // [mb][HQ_CPT * mb + 2] blocks of 16 words (split layout: 32), read with scalar loads (the next block's
+    // while this one is summed); for thread group g its t-th block, t = q mb + b, is block (b, g + q mb).
+    // Two words per shift s, shifts descending, k = 0 .. weight - 1:
+    //   word 2k      byte address of the record of row (Z - s) of block-row b, in the copy that belongs to the
+    //                edge's sign word (lane c adds 16 c)
+    //   word 2k + 1  s << 18 | edge number in the row's list << 5 | (31 - edge number mod 32)
+    //   word 14      weight of the block
+    //   word 16 + k  split layout: byte address of that row's sign word (lane c adds 4 c)
     const uint32_t *coltab;
 };
 

@@ -34,6 +34,7 @@ typedef __attribute__((address_space(3))) float lds_f32_t;
 typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
 typedef __attribute__((address_space(3))) u32x4 lds_u128_t;
 typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
 typedef const __attribute__((address_space(4))) u32x16 *tab512_t;     // constant address space: scalar loads
 
 // LDS by byte address: the kernel has no static LDS, so its dynamic LDS starts at address 0 (the host
@@ -44,6 +45,17 @@ __device__ __forceinline__ u32x4 ld_u128(uint32_t adr) { return *reinterpret_cas
 __device__ __forceinline__ void st_f32(uint32_t adr, float v) { *reinterpret_cast<lds_f32_t *>((uintptr_t)adr) = v; }
 __device__ __forceinline__ void st_u32(uint32_t adr, uint32_t v) { *reinterpret_cast<lds_u32_t *>((uintptr_t)adr) = v; }
 __device__ __forceinline__ void st_u128(uint32_t adr, u32x4 v) { *reinterpret_cast<lds_u128_t *>((uintptr_t)adr) = v; }
+
+#ifndef HQ_PRIO
+#define HQ_PRIO 1
+#endif
+__device__ __forceinline__ void hq_setprio(int p)
+{
+    if (p >= 3) __builtin_amdgcn_s_setprio(3);
+    else if (p == 2) __builtin_amdgcn_s_setprio(2);
+    else if (p == 1) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
+}
 
 __device__ __forceinline__ void hq_barrier()
 {
@@ -62,7 +74,7 @@ template <int NW> struct HqRow { uint32_t m1x, m2x, idx, sw[NW]; };
 // (checkNode.__init__, ldpc.py:121): v = posterior.
 template <int NW, bool FIRST, bool SPLIT>
 __device__ __forceinline__ unsigned long long
-hq_check_pass(uint32_t rt, int dpad, int deg, uint32_t i4, uint32_t my_rec, uint32_t my_sw, const HeavyGeom &G,
+hq_check_pass(uint32_t rt, uint32_t cw, int dpad, int deg, uint32_t i4, uint32_t my_rec, uint32_t my_sw, const HeavyGeom &G,
               HqRow<NW> &st, int sign_mode, float alpha, float beta, unsigned long long synd0)
 {
     enum { CH = HQ_CH, NCH = NW * 32 / CH };
@@ -99,8 +111,12 @@ hq_check_pass(uint32_t rt, int dpad, int deg, uint32_t i4, uint32_t my_rec, uint
         if (cc + 2 < NCH) issue_tab(cc + 2, tv[cc & 1]);
         __builtin_amdgcn_sched_barrier(0);
         const int w = cc * CH / 32;
+        // waves lower their own priority as they advance, so that the four of a SIMD finish the pass together
+        // instead of one after the other (the issue arbiter favours the oldest wave)
+        if (HQ_PRIO) hq_setprio(dpad > 48 ? 3 - cc / 2 : 3 - cc);
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
+            if (u == HQ_PAD && CH > HQ_PAD && cc * CH + u >= dpad) break;    // rows are padded to multiples of HQ_PAD (uniform)
             const int k = cc * CH % 32 + u;                              // bit 31 - k of word w
             const uint32_t e = (uint32_t)(cc * CH + u);
             const float p = pb[cc & 1][u];
@@ -130,6 +146,7 @@ hq_check_pass(uint32_t rt, int dpad, int deg, uint32_t i4, uint32_t my_rec, uint
             }
         }
     }
+    if (HQ_PRIO) __builtin_amdgcn_s_setprio(0);
     // left-align the words (first edge highest); the last edge that lowered the minimum is the arg-min
     uint32_t idx = 0;
 #pragma unroll
@@ -155,8 +172,10 @@ hq_check_pass(uint32_t rt, int dpad, int deg, uint32_t i4, uint32_t my_rec, uint
 #pragma unroll
     for (int w = 0; w < NW; ++w) st.sw[w] = nsw[w] ^ flip;
     // the row's record, at index i and at i + Z
+    // what a column compares its own edge's table word with: the table word of the arg-min edge
+    const uint32_t amw = ld_u32(cw + 4u * idx);
     if (SPLIT) {
-        const u32x4 r = {st.m1x, st.m2x, st.idx, 0u};
+        const u32x4 r = {st.m1x, st.m2x, amw, 0u};
         st_u128(my_rec, r);
         st_u128(my_rec + G.Z * 16, r);
 #pragma unroll
@@ -169,7 +188,7 @@ hq_check_pass(uint32_t rt, int dpad, int deg, uint32_t i4, uint32_t my_rec, uint
 #pragma unroll
         for (int w = 0; w < NW; ++w)
             if (32 * w < dpad) {
-                const u32x4 r = {st.m1x, st.m2x, st.idx, st.sw[w]};
+                const u32x4 r = {st.m1x, st.m2x, amw, st.sw[w]};
                 st_u128(my_rec + w * G.rec_wstride, r);
                 st_u128(my_rec + w * G.rec_wstride + G.Z * 16, r);
             }
@@ -181,34 +200,72 @@ hq_check_pass(uint32_t rt, int dpad, int deg, uint32_t i4, uint32_t my_rec, uint
 // ascending check index (ldpc.py:298-303): with the block's shifts descending, the rows c - s of the
 // shifts s <= c ascend, then come the wrapped rows c - s + Z of the shifts s > c, ascending as well.
 // An entry that is not its pass's turn adds +0, which changes no sum that started from +0.
-// E: the block's 16 table words (qc_heavy.h), in scalar registers.
+// E: the block's 16 table words (qc_heavy.h) in scalar registers, used as they are: word 2k is an address,
+// word 2k + 1 = s << 18 | edge << 5 | (31 - edge mod 32) is at once the shift amount that brings the edge's sign
+// to bit 0 (a shift looks at 5 bits), what the row record's third word equals if this edge got the second
+// minimum, and -- against cw = c << 18 | 0x3ffff -- the test "s > c".  SA: split layout, sign word addresses.
 template <int W, bool SPLIT>
-__device__ __forceinline__ float hq_block(const u32x16 &E, uint32_t c16, uint32_t c4, uint32_t c, float acc)
+__device__ __forceinline__ float hq_block(const u32x16 &E, const u32x8 &SA, uint32_t c16, uint32_t c4, uint32_t cw, float acc)
 {
     u32x4 R[W];
     uint32_t SW[W];
 #pragma unroll
     for (int k = 0; k < W; ++k) {
-        R[k] = ld_u128(c16 + (E[2 * k] & 0x3ffffu));
-        if (SPLIT) SW[k] = ld_u32(c4 + (E[2 * k + 1] & 0x3ffffu));
+        R[k] = ld_u128(c16 + E[2 * k]);
+        if (SPLIT) SW[k] = ld_u32(c4 + SA[k]);
     }
     float m[W];
 #pragma unroll
     for (int k = 0; k < W; ++k) {
-        const uint32_t e = (E[2 * k] >> 18) & 127u;
-        const uint32_t magx = R[k].z == e ? R[k].y : R[k].x;             // ldpc.py:190-191
-        const uint32_t ts = (SPLIT ? SW[k] : R[k].w) >> (31u - (e & 31u));
-        uint32_t mk;
+        const uint32_t magx = R[k].z == E[2 * k + 1] ? R[k].y : R[k].x;  // ldpc.py:190-191
+        uint32_t ts, mk;
+        asm("v_lshrrev_b32 %0, %1, %2" : "=v"(ts) : "s"(E[2 * k + 1]), "v"(SPLIT ? SW[k] : R[k].w));
         asm("v_alignbit_b32 %0, %1, %2, 1" : "=v"(mk) : "v"(ts), "v"(magx));
         m[k] = __uint_as_float(mk);
     }
     if (W == 1) return acc + m[0];
 #pragma unroll
-    for (int k = 0; k < W; ++k) acc = acc + ((E[2 * k + 1] >> 18) <= c ? m[k] : 0.0f);
+    for (int k = 0; k < W; ++k) acc = acc + (E[2 * k + 1] > cw ? 0.0f : m[k]);
 #pragma unroll
-    for (int k = 0; k < W; ++k) acc = acc + ((E[2 * k + 1] >> 18) > c ? m[k] : 0.0f);
+    for (int k = 0; k < W; ++k) acc = acc + (E[2 * k + 1] > cw ? m[k] : 0.0f);
     return acc;
 }
+
+template <bool SPLIT>
+__device__ __forceinline__ float hq_block_any(const u32x16 &E, const u32x8 &SA, uint32_t c16, uint32_t c4, uint32_t cw, float acc)
+{
+    switch (E[14]) {                                                     // the block's weight (uniform)
+    case 0: return acc;
+    case 1: return hq_block<1, SPLIT>(E, SA, c16, c4, cw, acc);
+    case 2: return hq_block<2, SPLIT>(E, SA, c16, c4, cw, acc);
+    case 3: return hq_block<3, SPLIT>(E, SA, c16, c4, cw, acc);
+    case 4: return hq_block<4, SPLIT>(E, SA, c16, c4, cw, acc);
+    case 5: return hq_block<5, SPLIT>(E, SA, c16, c4, cw, acc);
+    case 6: return hq_block<6, SPLIT>(E, SA, c16, c4, cw, acc);
+    default: return hq_block<7, SPLIT>(E, SA, c16, c4, cw, acc);
+    }
+}
+
+// One block's table words by scalar load; the matching wait names the registers, so that nothing reads them earlier.
+template <bool SPLIT>
+__device__ __forceinline__ void hq_tab_load(u32x16 &E, u32x8 &SA, tab512_t p)
+{
+    asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(E) : "s"(p));
+    if (SPLIT) asm volatile("s_load_dwordx8 %0, %1, 0x40" : "=s"(SA) : "s"(p));
+}
+template <bool SPLIT>
+__device__ __forceinline__ void hq_tab_wait(u32x16 &E, u32x8 &SA)
+{
+    if (SPLIT) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(E), "+s"(SA));
+    else asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(E));
+}
+
+#ifdef HQ_TRACE
+// phase timing (a build for tools/trace_heavy.py only): clock samples summed per wave, written once at the end
+#define HQ_T(k) { const unsigned long long now_ = __builtin_readcyclecounter(); tr_acc[k] += now_ - tr_t; tr_t = now_; }
+#else
+#define HQ_T(k)
+#endif
 
 template <int NW, bool SPLIT>
 __global__ void __launch_bounds__(1024)
@@ -227,16 +284,23 @@ qc_heavy_kernel(const HeavyTables tb, const DecodeArgs a)
     const uint32_t i4 = ic * 4, i16 = ic * 16;
     const int deg = tb.deg[g], dpad = tb.dpad[g];
     const uint32_t rt = G.rowtab_off + (uint32_t)g * 4u * G.tabw;
-    const tab512_t ct = (tab512_t)(uintptr_t)(tb.coltab + (size_t)g * (HQ_CPT * mb + 1) * HQ_BLK);
-    const int nblk = tb.ncol[g] * mb;                             // blocks of my columns
+    const uint32_t cwt = G.rowtab_off + ((uint32_t)mb + (uint32_t)g) * 4u * G.tabw;      // the edges' column-table words
+    enum { BLKW = SPLIT ? 2 * HQ_BLK : HQ_BLK };                  // table words per block
+    const tab512_t ct = (tab512_t)(uintptr_t)(tb.coltab + (size_t)g * (HQ_CPT * mb + 2) * BLKW);
+    const int ncol = tb.ncol[g], nblk = ncol * mb;               // my block-columns; their blocks
+    const uint32_t cwrap = (ic << 18) | 0x3ffffu;
+    const uint32_t col0 = ((uint32_t)g * G.Z2 + ic) * 4, colstep = (uint32_t)mb * G.Z2 * 4;      // my first column's posterior
     const uint32_t my_rec = G.rec_off + ((uint32_t)g * G.Z2 + ic) * 16;
     const uint32_t my_sw = G.sw_off + ((uint32_t)g * G.Z2 + ic) * 4;
     // padding edges read +inf: hard decision 1 each
     const unsigned long long synd0 = ((dpad - deg) & 1) ? __ballot(live) : 0ull;
     const uint32_t flags = G.flag_off;                            // [2] "syndrome non-zero", ones counter, claimed frame
 
+#ifdef HQ_TRACE
+    unsigned long long tr_acc[4] = {0, 0, 0, 0}, tr_t = 0;
+#endif
     for (int x = tid; x < Zp; x += NT) st_u32(G.dummy_off + 4u * x, 0x7f800000u);
-    for (int x = tid; x < mb * (int)G.tabw; x += NT) st_u32(G.rowtab_off + 4u * x, tb.rowtab[x]);
+    for (int x = tid; x < 2 * mb * (int)G.tabw; x += NT) st_u32(G.rowtab_off + 4u * x, tb.rowtab[x]);
 
     for (int64_t frame = blockIdx.x, next_frame = 0; frame < a.n_frames; frame = next_frame) {
         // ---- channel values; posterior := channel (decoderSet, ldpc.py:270-274)
@@ -281,16 +345,21 @@ qc_heavy_kernel(const HeavyTables tb, const DecodeArgs a)
 #pragma unroll
         for (int w = 0; w < NW; ++w) st.sw[w] = 0;
         int my_iters = 0, my_conv = 0;
+#ifdef HQ_TRACE
+        tr_t = __builtin_readcyclecounter();
+#endif
         for (int it = 0;; ++it) {
             const int par = it & 1;
             // ================= check pass (+ syndrome of the current posterior)
             if (live) {
                 const unsigned long long synd =
-                    it == 0 ? hq_check_pass<NW, true, SPLIT>(rt, dpad, deg, i4, my_rec, my_sw, G, st, a.sign_mode, a.ms_alpha, a.ms_beta, synd0)
-                            : hq_check_pass<NW, false, SPLIT>(rt, dpad, deg, i4, my_rec, my_sw, G, st, a.sign_mode, a.ms_alpha, a.ms_beta, synd0);
+                    it == 0 ? hq_check_pass<NW, true, SPLIT>(rt, cwt, dpad, deg, i4, my_rec, my_sw, G, st, a.sign_mode, a.ms_alpha, a.ms_beta, synd0)
+                            : hq_check_pass<NW, false, SPLIT>(rt, cwt, dpad, deg, i4, my_rec, my_sw, G, st, a.sign_mode, a.ms_alpha, a.ms_beta, synd0);
                 if (synd != 0ull && lane == 0) st_u32(flags + 4u * par, 1u);
             }
+            HQ_T(0);
             hq_barrier();
+            HQ_T(1);
             // ================= stop test (ldpc.py:332-335)
             const int bad = __builtin_amdgcn_readfirstlane((int)ld_u32(flags + 4u * par));
             if (bad == 0 || it >= a.max_iters) {
@@ -301,44 +370,56 @@ qc_heavy_kernel(const HeavyTables tb, const DecodeArgs a)
             if (tid == 0) st_u32(flags + 4u * (par ^ 1), 0u);
             // ================= variable pass (ldpc.py:295-311, 321-323)
             if (live) {
+                // Blocks in pairs: while one block's messages are fetched and summed, the next block's table words
+                // are on their way (asked for before this block's LDS traffic, waited for after it).
                 float acc = 0.0f;
-                int b = 0, q = 0;
-                u32x16 cur = ct[0];
-#pragma unroll 1
-                for (int t = 0; t < nblk; ++t) {
-                    // the next block's table words: asked for before this block's LDS traffic, waited for after it
-                    // (the table ends with a spare block)
-                    u32x16 nxt;
-                    asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(nxt) : "s"(ct + t + 1));
-                    switch ((cur[0] >> 25) & 15u) {
-                    case 0: break;
-                    case 1: acc = hq_block<1, SPLIT>(cur, i16, i4, ic, acc); break;
-                    case 2: acc = hq_block<2, SPLIT>(cur, i16, i4, ic, acc); break;
-                    case 3: acc = hq_block<3, SPLIT>(cur, i16, i4, ic, acc); break;
-                    case 4: acc = hq_block<4, SPLIT>(cur, i16, i4, ic, acc); break;
-                    case 5: acc = hq_block<5, SPLIT>(cur, i16, i4, ic, acc); break;
-                    case 6: acc = hq_block<6, SPLIT>(cur, i16, i4, ic, acc); break;
-                    case 7: acc = hq_block<7, SPLIT>(cur, i16, i4, ic, acc); break;
-                    default: acc = hq_block<8, SPLIT>(cur, i16, i4, ic, acc); break;
-                    }
+                int b = 0, done = 0;
+                uint32_t col = col0;
+                auto end_of_block = [&]() {
                     if (++b == mb) {
-                        // the column's last block-row: add the channel value (last, ldpc.py:322) and store
-                        float yq = y[0];
+                        // the column's last block-row: add the channel value (last, ldpc.py:322) and store; the
+                        // channel values rotate, so that y[0] is always the current column's
+                        const float yq = y[0];
 #pragma unroll
-                        for (int qq = 1; qq < HQ_CPT; ++qq) yq = q == qq ? y[qq] : yq;
-                        const float post = acc + yq;
-                        const uint32_t adr = ((uint32_t)(g + q * mb) * G.Z2 + ic) * 4;
-                        st_f32(adr, post);
-                        st_f32(adr + G.Z * 4, post);
+                        for (int qq = 0; qq + 1 < HQ_CPT; ++qq) y[qq] = y[qq + 1];
+                        y[HQ_CPT - 1] = yq;
+                        if (done < ncol) {
+                            const float post = acc + yq;
+                            st_f32(col, post);
+                            st_f32(col + G.Z * 4, post);
+                        }
+                        col += colstep;
                         acc = 0.0f;
                         b = 0;
-                        ++q;
+                        ++done;
                     }
-                    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(nxt));
-                    cur = nxt;
+                };
+                u32x16 EA, EB;
+                u32x8 SA, SB;
+                hq_tab_load<SPLIT>(EA, SA, ct);
+                hq_tab_wait<SPLIT>(EA, SA);
+#pragma unroll 1
+                for (int t = 0; t < nblk; t += 2) {                      // (the table ends with two spare blocks)
+                    hq_tab_load<SPLIT>(EB, SB, (tab512_t)((const __attribute__((address_space(4))) uint32_t *)ct + (size_t)(t + 1) * BLKW));
+                    acc = hq_block_any<SPLIT>(EA, SA, i16, i4, cwrap, acc);
+                    end_of_block();
+                    hq_tab_wait<SPLIT>(EB, SB);
+                    hq_tab_load<SPLIT>(EA, SA, (tab512_t)((const __attribute__((address_space(4))) uint32_t *)ct + (size_t)(t + 2) * BLKW));
+                    acc = hq_block_any<SPLIT>(EB, SB, i16, i4, cwrap, acc);
+                    end_of_block();
+                    hq_tab_wait<SPLIT>(EA, SA);
+                }
+#pragma unroll 1
+                for (; done < HQ_CPT; ++done) {                          // the rotation comes full circle
+                    const float yq = y[0];
+#pragma unroll
+                    for (int qq = 0; qq + 1 < HQ_CPT; ++qq) y[qq] = y[qq + 1];
+                    y[HQ_CPT - 1] = yq;
                 }
             }
+            HQ_T(2);
             hq_barrier();
+            HQ_T(3);
         }
 
         // ================= outputs
@@ -354,6 +435,7 @@ qc_heavy_kernel(const HeavyTables tb, const DecodeArgs a)
             if (a.hard) a.hard[frame * nbytes + x] = (uint8_t)byte;
             if (byte) __hip_atomic_fetch_add(reinterpret_cast<lds_u32_t *>((uintptr_t)(flags + 8)), (uint32_t)__popc(byte), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
+#ifndef HQ_TRACE
         if (a.soft && live) {
             float *so = reinterpret_cast<float *>(a.soft) + frame * n;
 #pragma unroll
@@ -362,6 +444,7 @@ qc_heavy_kernel(const HeavyTables tb, const DecodeArgs a)
                 if (j < nb) so[j * Z + (int)ic] = ld_f32(((uint32_t)j * G.Z2 + ic) * 4);
             }
         }
+#endif
         hq_barrier();
         if (tid == 0) {
             if (a.iters) a.iters[frame] = my_iters;
@@ -370,6 +453,11 @@ qc_heavy_kernel(const HeavyTables tb, const DecodeArgs a)
         }
         hq_barrier();
     }
+#ifdef HQ_TRACE
+    if (lane == 0 && a.soft)
+        for (int k = 0; k < 4; ++k)
+            reinterpret_cast<unsigned long long *>(a.soft)[((size_t)blockIdx.x * 16 + (tid >> 6)) * 4 + k] = tr_acc[k];
+#endif
 }
 
 }  // namespace

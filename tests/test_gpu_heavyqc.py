@@ -14,13 +14,13 @@ def heavy_lds_bytes(qc):
     how the tests tell which kernel a handle launches."""
     Z, mb, nb = qc.Z, qc.mb, qc.nb
     Zp = (Z + 63) // 64 * 64
-    dpad = (max(qc.row_degrees()) + 7) // 8 * 8
+    dpad = (max(qc.row_degrees()) + 3) // 4 * 4
     nwu = (dpad + 31) // 32
     split = nwu > 2
     rec_off = (nb * 2 * Z * 4 + Zp * 4 + 15) & ~15
     sw_off = rec_off + (1 if split else nwu) * mb * 2 * Z * 16
     flag_off = sw_off + (nwu * mb * 2 * Z * 4 if split else 0)
-    return flag_off + 16 + mb * 32 * (2 if nwu <= 2 else 4) * 4
+    return flag_off + 16 + 2 * mb * 32 * (2 if nwu <= 2 else 4) * 4
 
 
 def episode(n_actions, seed=20211227):
@@ -124,7 +124,7 @@ def test_small_codes_and_other_geometries(oracle_mod, monkeypatch):
     from ldpc_amd import codes
     prng = np.random.RandomState(99)
     monkeypatch.setenv('LDPC_HIP_FORCE_HEAVYQC', '1')
-    for (Z, mb, nb, wmax) in ((81, 4, 24, 3), (37, 3, 10, 5), (128, 2, 9, 8), (200, 4, 13, 4)):
+    for (Z, mb, nb, wmax) in ((81, 4, 24, 3), (37, 3, 10, 5), (128, 2, 9, 7), (200, 4, 13, 4)):
         blocks = []
         for b in range(mb):
             row = []
