@@ -1637,7 +1637,8 @@ extern "C" int ldpc_create_qc(int device, int Z, int mb, int nb, const int32_t *
         const int nwu = (dpad_max + 31) / 32;
         const HeavyGeom geo(Z, Zp, mb, nb, nwu);
         // one frame per workgroup: worth it where the table-driven kernel holds one frame per workgroup too
-        const bool wanted = forced || (!h->planes_ok && !h->is_regular && mb * Zp > 512);
+        // (and where the short-code kernels do not apply: they take checks of up to 24 edges)
+        const bool wanted = forced || (!h->planes_ok && !h->is_regular && mb * Zp > 512 && max_deg > 24);
         if (wanted && !(off && off[0] == '1') && mb <= HQ_MAXMB && h->cols_per_thread <= HQ_CPT && max_w <= HQ_WMAX &&
             min_deg >= 2 && max_deg <= 32 * HQ_NW && Z <= 1023 && (size_t)geo.bytes <= h->lds_max) {
             HeavyTables &t = h->heavyqc;
@@ -1696,7 +1697,9 @@ extern "C" int ldpc_create_qc(int device, int Z, int mb, int nb, const int32_t *
     // the same graph as an edge list: now, unless the message-plane kernels take the code (then on first need)
     {
         const char *eager = hook("LDPC_HIP_EAGER_EDGES");
-        if ((h->planes_ok || h->heavyqc_ok) && !(eager && eager[0] == '1')) {
+        const char *force_hq = hook("LDPC_HIP_FORCE_HEAVYQC");
+        const bool heavy_by_choice = h->heavyqc_ok && !(force_hq && force_hq[0] == '1');
+        if ((h->planes_ok || heavy_by_choice) && !(eager && eager[0] == '1')) {
             h->qc_blk_ptr.assign(blk_ptr, blk_ptr + nblk + 1);
             h->qc_shifts.assign(shifts, shifts + blk_ptr[nblk]);
         } else if ((rc = stage_qc_edges(h, blk_ptr, shifts))) {
