@@ -1,5 +1,6 @@
 """Parity at scale (-m gpu): 10^5 NearEarth frames at 3.3 dB (frames that stop early, late and not at
-all) through the C ABI against the CPU oracle, float32 and float64, frame for frame; and the
+all) through the C ABI against the CPU oracle, float32 and float64, frame for frame; the 10^6 frames at
+3.5 dB of the headline figure in float32; and the
 sum-product kernels against the CPU statement of the same precision on 2*10^4 frames per code.
 Channel values come from the device generator (any values do: both sides decode the same array)."""
 import numpy as np
@@ -39,6 +40,44 @@ def test_minsum_1e5_frames_bit_exact(oracle_mod):
             # the batch holds what it is meant to hold: early, late and failed frames
             assert iters.min() <= 6 and 0.01 < (conv == 0).mean() < 0.6 and ((iters > 25) & (conv == 1)).sum() > 50
             del hard, r
+
+
+def test_minsum_1e6_frames_bit_exact(oracle_mod):
+    """The size the headline figure is quoted on: 10^6 NearEarth frames at 3.5 dB, <= 50 iterations, float32
+    (the arithmetic of the reference's GPU path, ldpcCUDA.py:538-548), decoded where they are made -- on the
+    device, through ldpc_decode_device -- against the CPU oracle on the same values, frame for frame: hard
+    decisions, iteration counts, status, error counts.  Slices of 10^5 frames; the oracle (16 host threads, about
+    40 s in all) is most of the test's time."""
+    import torch
+    import ldpc_amd
+    qc, H = build_code('nearEarth')
+    orc = oracle_mod.Oracle(H)
+    F, S = 1_000_000, 100_000
+    tot = dict(frames=0, iters=0, failed=0)
+    with ldpc_amd.Decoder(qc) as eng:
+        assert eng.launch_info(prec=32)['lds_bytes'] == 163824          # the message-plane kernel of the headline
+        eng.set_stream(torch.cuda.current_stream().cuda_stream)
+        llr = torch.empty((S, eng.n), dtype=torch.float32, device='cuda:0')
+        d_hard = torch.empty((S, eng.nbytes), dtype=torch.uint8, device='cuda:0')
+        d_iters = torch.empty(S, dtype=torch.int32, device='cuda:0')
+        d_conv = torch.empty(S, dtype=torch.uint8, device='cuda:0')
+        d_ones = torch.empty(S, dtype=torch.int32, device='cuda:0')
+        for first in range(0, F, S):
+            eng.channel_awgn_device(llr, S, 3.5, seed=460101, first_frame=first)
+            eng.decode_device(llr, S, 50, prec=32, d_hard=d_hard, d_iters=d_iters, d_conv=d_conv, d_ones=d_ones)
+            torch.cuda.synchronize()
+            hard, iters, conv, _ = orc.minsum(llr.cpu().numpy(), 50, prec=32, threads=THREADS, want_soft=False)
+            g_hard = np.unpackbits(d_hard.cpu().numpy(), axis=1, bitorder='little')[:, :eng.n]
+            bad = np.flatnonzero((d_iters.cpu().numpy() != iters) | (d_conv.cpu().numpy() != conv) |
+                                 (g_hard != hard).any(axis=1) | (d_ones.cpu().numpy() != hard.sum(1, dtype=np.int64)))
+            assert bad.size == 0, (first, (first + bad[:10]).tolist())
+            tot['frames'] += S
+            tot['iters'] += int(iters.sum())
+            tot['failed'] += int((conv == 0).sum())
+            del hard, g_hard
+        eng.set_stream(None)
+    print(f"{tot['frames']} frames identical; mean iterations {tot['iters'] / F:.3f}, {tot['failed']} frames do not converge")
+    assert tot['frames'] == F and 6.5 < tot['iters'] / F < 7.5 and 1000 < tot['failed'] < 5000
 
 
 @pytest.mark.parametrize('name,snr,sign_mode,bar', [('nearEarth', 3.3, 0, 0.9999), ('wifi_5_6', 4.0, 1, 0.9999),
