@@ -1,7 +1,8 @@
 """Worker of the multi-process tests (started by torch.distributed.run, one process per rank).
 mode fake: the local evaluation is a deterministic function of (SNR index, global frame
 number) -- no decoding -- so the partition, the counter reduction and the per-frame gather
-can be checked on CPU ranks.  mode gpu: the real engine on cuda:0 (ranks share the card)."""
+can be checked on CPU ranks.  mode gpu: the real engine on cuda:0 (ranks share the card, counters
+reduced over gloo).  mode nccl: the real engine, one rank per card, counters and per-frame data over RCCL."""
 import json
 import os
 import sys
@@ -35,7 +36,7 @@ def fake_variant(variant, snr, frames, seed):
 def main():
     mode, out_path = sys.argv[1], sys.argv[2]
     from ldpc_amd import distributed as D
-    D.init('gloo')
+    D.init('nccl' if mode == 'nccl' else 'gloo')
     rank, _, ws = D.world()
     res = {}
     if mode == 'fake':

@@ -89,3 +89,50 @@ def test_bench_spawns_its_own_ranks():
     one = run(1, 40000)
     assert two['n_gpus'] == 2 and one['n_gpus'] == 1
     assert two['stats'] == one['stats'] and two['stats']['frames'] == 40000
+
+
+def _cards():
+    import torch
+    return torch.cuda.device_count()          # (counting devices does not initialise the GPU runtime)
+
+
+@pytest.mark.gpu
+def test_sharded_sweep_over_rccl_one_rank_per_card(tmp_path):
+    """The reference's device fan-out (ldpcCUDA.py:891-906) as this package does it: one process per card,
+    frames sharded by global frame number, counters all-reduced and per-frame columns all-gathered over RCCL.
+    Skipped on a one-card box; on a node with several cards the result must equal one rank's."""
+    n = _cards()
+    if n < 2:
+        pytest.skip('one rank per GPU over RCCL: needs two cards or more')
+    one = run_world(1, 'gpu', tmp_path)
+    for ws in sorted({2, min(n, 8)}):
+        many = run_world(ws, 'nccl', tmp_path)
+        assert one['cnt'] == many['cnt'], ws
+        assert one['pf'] == many['pf'], ws
+        assert one['var'] == many['var'], ws
+
+
+@pytest.mark.gpu
+def test_bench_over_rccl_equals_gloo_rehearsal():
+    """Plain `python bench.py --gpus 2`, one rank per card, counters all-reduced over RCCL: the same statistics as
+    the two-rank gloo rehearsal on one card and as one rank decoding all the frames.  Skipped on a one-card box."""
+    if _cards() < 2:
+        pytest.skip('one rank per GPU over RCCL: needs two cards or more')
+    base = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'LDPC_BENCH_BACKEND')}
+
+    def run(gpus, frames, backend):
+        env = dict(base)
+        if backend:
+            env['LDPC_BENCH_BACKEND'] = backend
+        p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(gpus), '--frames', str(frames),
+                            '--steps', '2', '--warmup', '1', '--no-cpu', '--no-secondary'], capture_output=True, text=True,
+                           timeout=600, env=env, cwd=ROOT)
+        assert p.returncode == 0, p.stderr[-3000:]
+        lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{')]
+        assert len(lines) == 1
+        return json.loads(lines[0])
+    rccl = run(2, 20000, None)
+    gloo = run(2, 20000, 'gloo')
+    one = run(1, 40000, None)
+    assert rccl['n_gpus'] == 2 and rccl['config']['parallelism'].startswith('frames sharded over 2')
+    assert rccl['stats'] == gloo['stats'] == one['stats'] and rccl['stats']['frames'] == 40000
