@@ -30,9 +30,11 @@ def build(force=False):
 def lib():
     global _LIB
     if _LIB is None:
-        so = os.path.join(_HERE, 'libldpc_oracle.so')
-        if not os.path.exists(so):
-            build()
+        so = os.environ.get('LDPC_ORACLE_SO')            # another build of the same sources (oracle/Makefile: asan)
+        if not so:
+            so = os.path.join(_HERE, 'libldpc_oracle.so')
+            if not os.path.exists(so):
+                build()
         L = ctypes.CDLL(so)
         L.oracle_graph_create.restype = ctypes.c_void_p
         L.oracle_graph_create.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
