@@ -42,7 +42,7 @@ def cpu_baseline(llr_dev, n_frames, n_threads, slice_frames=16384):
         m = min(slice_frames, n_frames - done)
         y = llr_dev[done:done + m].cpu().numpy().astype(np.float64)
         if t1 is None:
-            one = min(m, 512)
+            one = min(m, 4096)
             t0 = time.perf_counter()
             orc.minsum(y[:one], 50, prec=64, want_soft=False, threads=1)
             t1 = time.perf_counter() - t0
@@ -71,13 +71,43 @@ def wilson(k, n, z=1.96):
 
 
 def cpu_model():
+    """What /proc/cpuinfo says about the first core: model name (virtual machines often shorten it), family /
+    model / stepping, clock and the widest vector extension."""
+    want = {'model name': None, 'cpu family': None, 'model': None, 'stepping': None, 'cpu MHz': None, 'flags': ''}
     try:
         for line in open('/proc/cpuinfo'):
-            if line.startswith('model name'):
-                return line.split(':', 1)[1].strip()
+            k, _, v = line.partition(':')
+            k = k.strip()
+            if k in want and not want[k]:
+                want[k] = v.strip()
+            if not line.strip():
+                break
     except OSError:
-        pass
-    return None
+        return None
+    flags = want['flags'].split()
+    simd = next((f for f in ('avx512f', 'avx2', 'avx', 'sse4_2') if f in flags), None)
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = None
+    return {'model_name': want['model name'], 'family_model_stepping': [want['cpu family'], want['model'], want['stepping']],
+            'mhz': want['cpu MHz'], 'widest_simd': simd, 'cores_this_process_may_use': usable}
+
+
+def library_source_sha16():
+    """Fingerprint of the sources libldpc_hip.so is built from (the GPU box has no git history to ask): the
+    committed counter passes carry the fingerprint they were taken on, and a figure read from them is marked
+    stale when the library has changed since."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, 'ldpc_amd', 'csrc', '*.h')) + glob.glob(os.path.join(ROOT, 'ldpc_amd', 'csrc', '*.hip')) +
+                   glob.glob(os.path.join(ROOT, 'ldpc_amd', 'csrc', '*.cc')) + [os.path.join(ROOT, 'ldpc_amd', 'csrc', 'Makefile'),
+                                                                              os.path.join(ROOT, 'include', 'ldpc_hip.h')])
+    for f in files:
+        h.update(os.path.basename(f).encode() + b'\0')
+        h.update(open(f, 'rb').read())
+    return h.hexdigest()[:16]
 
 
 def committed_counters(prec, frames, spa):
@@ -93,7 +123,10 @@ def committed_counters(prec, frames, spa):
         if not e:
             return None, None, None
         onchip = {k: e[k] for k in ('valu_busy_frac', 'lds_busy_frac') if k in e}
+        now = library_source_sha16()
         src = {'file': 'profiles/hbm_traffic.json', 'summary': e.get('source'), 'library_commit': e.get('library_commit'),
+               'library_source_sha16': e.get('library_source_sha16'), 'library_source_sha16_now': now,
+               'stale': e.get('library_source_sha16') != now,
                'taken': e.get('taken'), 'measured_in_this_run': False}
         return e['hbm_bytes_per_launch'], onchip, src
     except Exception:
@@ -288,10 +321,14 @@ def main():
     ap.add_argument('--no-secondary', action='store_true',
                     help='skip the untimed secondary configurations measured after the headline region')
     ap.add_argument('--seed', type=int, default=460101)
+    ap.add_argument('--print-source-sha', action='store_true', help='print the fingerprint of the library sources and exit')
     ap.add_argument('--fixed50', action='store_true',
                     help='also time one launch at 0 dB, where every frame runs all 50 iterations (extra field; off by '
                          'default so that a profile of the default command sees only identical launches)')
     args = ap.parse_args()
+    if args.print_source_sha:
+        print(library_source_sha16())
+        return
 
     # --gpus N with no launcher around this process: start the N ranks here (before torch or HIP
     # is touched) and relay rank 0's line.  Under torch.distributed.run the launcher's world wins,

@@ -16,12 +16,12 @@ PROF_SCRIPT=tools/prof_sweep.py bash tools/pmc_passes.sh $O/pmc_sweep --frames 1
 python3 tools/pmc_summary.py $O/pmc_sweep 1000000 21 $O/f32_fused_sweep_pmc_summary.json "tools/pmc_passes.sh: python3 tools/prof_sweep.py --frames 1000000 --snr 3.5 (library commit $COMMIT); algorithmic bytes per frame = iterations 4 + status 1 + ones 4 + uncoded 4 + noise sum 8" > /dev/null || { echo sweep summary failed; exit 1; }
 timeout -k 10 240 python3 tools/bench_codes.py > $O/secondary.json 2> $O/secondary.err || { echo secondary failed; exit 1; }
 timeout -k 10 240 python3 tools/bench_heavy.py > $O/heavy.json 2> $O/heavy.err || { echo heavy failed; exit 1; }
-python3 - $O $COMMIT <<'PY'
+python3 - $O $COMMIT $(python3 bench.py --print-source-sha) <<'PY'
 import json, sys, time
-o, commit = sys.argv[1], sys.argv[2]
+o, commit, sha = sys.argv[1], sys.argv[2], sys.argv[3]
 s = json.load(open(o + '/f32_planes_pmc_summary.json'))['derived']
 json.dump({'prec32_frames1000000': {'hbm_bytes_per_launch': s['hbm_bytes_per_launch'], 'source': 'profiles/%s_f32_planes_pmc_summary.json' % o.split('/')[-1],
-                                    'library_commit': commit, 'taken': time.strftime('%Y-%m-%d'),
+                                    'library_commit': commit, 'library_source_sha16': sha, 'taken': time.strftime('%Y-%m-%d'),
                                     'valu_busy_frac': s['valu_busy_frac'], 'lds_busy_frac': s['lds_busy_frac']}},
           open(o + '/hbm_traffic.json', 'w'), indent=1)
 PY
