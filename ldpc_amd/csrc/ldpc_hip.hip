@@ -1854,7 +1854,8 @@ static int reg_pick(const ldpc_handle *h, Launch *L)
 static bool planes_applies(const ldpc_handle *h, int prec, bool chained, bool spa = false)
 {
     const char *off = hook("LDPC_HIP_NO_PLANES");
-    return h->planes_ok && prec == 32 && !chained && !(spa && h->planes_heavy) &&
+    (void)spa;
+    return h->planes_ok && prec == 32 && !chained &&
            (size_t)PlanesGeom<511, 8>::LDS_BYTES <= h->lds_max && !(off && off[0] == '1');
 }
 
@@ -1862,13 +1863,20 @@ static int planes_pick(const ldpc_handle *h, bool spa, Launch *L)
 {
     // LDPC_HIP_FORCE_HEAVY=1 (test hook): the heavy-circulant kernel for a code without heavy circulants
     const char *force = hook("LDPC_HIP_FORCE_HEAVY");
-    if (h->planes_heavy || (!spa && force && force[0] == '1')) {
+    if (h->planes_heavy || (force && force[0] == '1')) {
         const bool small = h->planes.n_extra[0] <= PlanesHeavy<1>::MX && h->planes.n_extra[1] <= PlanesHeavy<1>::MX &&
                            h->planes_max_w <= PlanesHeavy<1>::MW;
-        L->fn = small ? reinterpret_cast<const void *>(&qc_planes_kernel<511, 8, false, false, 1>)
-                      : reinterpret_cast<const void *>(&qc_planes_kernel<511, 8, false, false, 2>);
-        L->fn_gen = small ? reinterpret_cast<const void *>(&qc_planes_kernel<511, 8, false, true, 1>)
-                          : reinterpret_cast<const void *>(&qc_planes_kernel<511, 8, false, true, 2>);
+        if (spa) {
+            L->fn = small ? reinterpret_cast<const void *>(&qc_planes_kernel<511, 8, true, false, 1>)
+                          : reinterpret_cast<const void *>(&qc_planes_kernel<511, 8, true, false, 2>);
+            L->fn_gen = small ? reinterpret_cast<const void *>(&qc_planes_kernel<511, 8, true, true, 1>)
+                              : reinterpret_cast<const void *>(&qc_planes_kernel<511, 8, true, true, 2>);
+        } else {
+            L->fn = small ? reinterpret_cast<const void *>(&qc_planes_kernel<511, 8, false, false, 1>)
+                          : reinterpret_cast<const void *>(&qc_planes_kernel<511, 8, false, false, 2>);
+            L->fn_gen = small ? reinterpret_cast<const void *>(&qc_planes_kernel<511, 8, false, true, 1>)
+                              : reinterpret_cast<const void *>(&qc_planes_kernel<511, 8, false, true, 2>);
+        }
         L->ws_stride = std::max<size_t>((size_t)h->planes.xstride * sizeof(float), 256);
     } else {
         L->fn = spa ? reinterpret_cast<const void *>(&qc_planes_kernel<511, 8, true, false, 0>)

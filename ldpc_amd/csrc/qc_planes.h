@@ -131,7 +131,8 @@ struct PlanesXState {
     {
         return (x & 1) ? (xadr2[x >> 1] >> 14) & 0x3fffcu : (xadr2[x >> 1] << 2) & 0x3fffcu;
     }
-    float pm1, pm2;                  // the two magnitudes sent
+    float cprev[PLANES_MAXX];        // sum-product: the message sent along each extra edge (they all differ)
+    float pm1, pm2;                  // min-sum: the two magnitudes sent
     uint32_t pidx;                   // edge that got pm2: 0..31 slot edges, 32 + x extra x
     uint32_t psign;                  // bit x: the message on extra x was negative
     float *xbase;                    // this workgroup's scratch rows (uniform)
@@ -407,16 +408,40 @@ __device__ __forceinline__ float planes_phi(float x)
 // Sum-product check pass (the rule stated with csr_spa_kernel): same structure as the min-sum
 // pass; the message slot of an edge holds F_e = phi|v_e| between the two halves.
 // HOLES: some edge of the row may be missing (its record is the dummy, |v| = inf): such an edge adds no term.
-template <int Z, int CPT, int B, bool FIRST, bool HOLES>
+// HV > 0: the row's extra edges (heavy circulants) come first; the F of each stays in a register between the
+// two halves, its outgoing message goes to the scratch row (and stays in xs.cprev for the next iteration).
+template <int Z, int CPT, int B, bool FIRST, bool HOLES, int HV = 0>
 __device__ __forceinline__ unsigned long long
 planes_check_pass_spa(unsigned char *smem, const uint32_t (&radr)[CPT * 4], int D, int sign_mode,
-                      unsigned long long synd0)
+                      unsigned long long synd0, PlanesXState &xs)
 {
     typedef PlanesGeom<Z, CPT> G;
-    enum { NS = G::NS, CH = 4, NCH = NS / CH };
+    enum { NS = G::NS, CH = 4, NCH = NS / CH, HEAVY = HV > 0, MX = PlanesHeavy<HV>::MX };
     float F1 = 0.0f, rest = 0.0f;          // F > 0 always, so the first edge displaces the initial 0 (rest += 0)
     uint32_t GT = 0, R = 0;
     unsigned long long synd = synd0;     // set for every row if rows have an odd number of missing edges (each reads as hard decision 1)
+    uint32_t RX = 0, idxx = 0;           // extra edges: bit x = v < 0; the one that holds the largest term so far (NS + x)
+    float fx[MX > 0 ? MX : 1];
+    if (HEAVY) {
+        float px[MX > 0 ? MX : 1];
+#pragma unroll
+        for (int x = 0; x < MX; ++x) px[x] = x < xs.X ? lds_f32(smem, xs.xadr(x)) : 0.0f;
+#pragma unroll
+        for (int x = 0; x < MX; ++x) {
+            fx[x] = 0.0f;
+            if (x < xs.X) {
+                synd ^= __ballot(px[x] > 0.0f);
+                const float v = FIRST ? px[x] : px[x] - xs.cprev[x];
+                RX |= (__float_as_uint(v) >> 31) << x;
+                const float F = planes_phi(__builtin_amdgcn_fmed3f(fabsf(v), 1e-12f, 80.0f));
+                fx[x] = F;
+                idxx = F > F1 ? (uint32_t)(NS + x) : idxx;
+                const float hi = fmaxf(F1, F), lo = fminf(F1, F);
+                rest = rest + lo;
+                F1 = hi;
+            }
+        }
+    }
     float p[2][CH], c[2][CH];
 #pragma unroll
     for (int k = -1; k < NCH; ++k) {
@@ -463,9 +488,11 @@ planes_check_pass_spa(unsigned char *smem, const uint32_t (&radr)[CPT * 4], int 
         __builtin_amdgcn_sched_barrier(0);
     }
     if (NS < 32) GT <<= (32 - NS);
-    const uint32_t idx = GT != 0u ? 31u - (uint32_t)__builtin_ctz(GT) : 0u;
+    // the last edge that raised the largest term strictly holds it: a slot edge, or else an extra edge
+    const uint32_t idx = GT != 0u ? 31u - (uint32_t)__builtin_ctz(GT) : (HEAVY ? idxx : 0u);
     if (NS < 32) R <<= (32 - NS);
     uint32_t S = __popc(R) & 1u;
+    if (HEAVY) S ^= __popc(RX) & 1u;
     if (sign_mode == LDPC_SIGN_CORRECTED) S ^= (uint32_t)D & 1u;       // D: the row's real degree
     const uint32_t full = 0xffffffffu << (32 - NS);
     const uint32_t T = R ^ (S ? full : 0u);
@@ -497,6 +524,18 @@ planes_check_pass_spa(unsigned char *smem, const uint32_t (&radr)[CPT * 4], int 
         }
         __builtin_amdgcn_sched_barrier(0);
     }
+    if (HEAVY) {
+        const uint32_t SX = RX ^ (S ? 0xffffffffu : 0u);
+#pragma unroll
+        for (int x = 0; x < MX; ++x)
+            if (x < xs.X) {
+                const float xe = idx == (uint32_t)(NS + x) ? rest : (rest - fx[x]) + F1;
+                const float mag = planes_phi(__builtin_amdgcn_fmed3f(xe, 1e-12f, 80.0f));
+                const float msg = __uint_as_float(__float_as_uint(mag) | (((SX >> x) & 1u) << 31));
+                xs.cprev[x] = msg;
+                xs.xbase[opaque(xs.xoff) + (uint32_t)(x * PLANES_XROW)] = msg;
+            }
+    }
     return synd;
 }
 
@@ -511,7 +550,6 @@ __device__ __forceinline__ void
 planes_role(unsigned char *smem, const PlanesTables &tb, const DecodeArgs &a)
 {
     enum { HEAVY = HV > 0, MX = PlanesHeavy<HV>::MX, MW = PlanesHeavy<HV>::MW, CANON = PLANES_CANON && !SPA && !HEAVY };
-    static_assert(!(HEAVY && SPA), "heavy circulants: min-sum only");
     typedef PlanesGeom<Z, CPT> G;
     enum { MB = G::MB, W = G::W, NB = G::NB, NS = G::NS, N = G::N, ZP = G::ZP, CB = G::CB,
            NT = MB * G::ZP };                    // threads per workgroup
@@ -846,8 +884,8 @@ planes_role(unsigned char *smem, const PlanesTables &tb, const DecodeArgs &a)
         {
             if (live) {
                 const unsigned long long synd = SPA
-                    ? (D == NS ? planes_check_pass_spa<Z, CPT, B, true, false>(smem, radr, D, a.sign_mode, synd0)
-                               : planes_check_pass_spa<Z, CPT, B, true, true>(smem, radr, D, a.sign_mode, synd0))
+                    ? (D - xs.X == NS ? planes_check_pass_spa<Z, CPT, B, true, false, HV>(smem, radr, D, a.sign_mode, synd0, xs)
+                                      : planes_check_pass_spa<Z, CPT, B, true, true, HV>(smem, radr, D, a.sign_mode, synd0, xs))
                     : planes_check_pass<Z, CPT, B, true, HV, CANON>(smem, radr, D, a.sign_mode, ic, synd0, a.ms_alpha, a.ms_beta, xs);
                 // flags[parity]: number of rows whose check fails (bit 20: raised by the syndrome-only pass)
                 if (synd != 0ull && lane == 0) atomicAdd(&flags[0], (int)__popcll(synd));
@@ -902,8 +940,8 @@ planes_role(unsigned char *smem, const PlanesTables &tb, const DecodeArgs &a)
                     }
                     if (live) {
                         const unsigned long long synd = SPA
-                            ? (D == NS ? planes_check_pass_spa<Z, CPT, B, false, false>(smem, radr, D, a.sign_mode, synd0)
-                                       : planes_check_pass_spa<Z, CPT, B, false, true>(smem, radr, D, a.sign_mode, synd0))
+                            ? (D - xs.X == NS ? planes_check_pass_spa<Z, CPT, B, false, false, HV>(smem, radr, D, a.sign_mode, synd0, xs)
+                                              : planes_check_pass_spa<Z, CPT, B, false, true, HV>(smem, radr, D, a.sign_mode, synd0, xs))
                             : planes_check_pass<Z, CPT, B, false, HV, CANON>(smem, radr, D, a.sign_mode, ic, synd0, a.ms_alpha, a.ms_beta, xs);
                         if (synd != 0ull && lane == 0) atomicAdd(&flags[par], (int)__popcll(synd));
                     }

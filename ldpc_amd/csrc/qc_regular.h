@@ -29,11 +29,14 @@ struct RegTables {
 
 template <typename T> struct RegState;
 // float: {min1, min2, sign bits (left aligned, pre-multiplied by the row's sign product), argmin slot}
-template <> struct RegState<float> { enum { BYTES = 16 }; };
-// double: {sign bits, argmin slot} {min1} {min2}: the variable pass reads the first 8 bytes, then only the
-// magnitude it needs (16 bytes per edge instead of 24; the pass is bound by LDS traffic).  A stride of
-// 24 bytes also keeps the 8-byte reads of 16 consecutive rows on distinct banks.
-template <> struct RegState<double> { enum { BYTES = 24 }; };
+template <> struct RegState<float> { enum { BYTES = 16, STRIDE = 16 }; };
+// double: {sign bits, arg-min edge} {min1} {min2}, 8 bytes each: the variable pass reads a row's first 8 bytes, then
+// only the magnitude it needs (16 bytes per edge instead of 24; the pass is bound by LDS traffic).  The three parts
+// of a row sit side by side (stride 24 bytes) or, with REG_F64_PLANES, in three planes of `plane` bytes each.
+#ifndef REG_F64_PLANES
+#define REG_F64_PLANES 0             // 1: three planes of 8 bytes per row instead of the interleaved 24 bytes -- LDS bank conflicts 19.9 % -> 9.1 % of the LDS cycles, yet 1.3 % slower (the kernel is bound by vector issue); kept for comparison
+#endif
+template <> struct RegState<double> { enum { BYTES = 24, STRIDE = REG_F64_PLANES ? 8 : 24 }; };
 
 __device__ __forceinline__ uint32_t hi_bits(float v) { return __float_as_uint(v); }
 __device__ __forceinline__ uint32_t hi_bits(double v) { return (uint32_t)__double2hiint(v); }
@@ -60,16 +63,16 @@ __device__ __forceinline__ V lds_load(uint32_t abs_addr)
     return *(const __attribute__((address_space(3))) V *)(uintptr_t)abs_addr;
 }
 
-__device__ __forceinline__ void lds_store_state(unsigned char *smem, uint32_t addr, const RowStateRegs<float> &s)
+__device__ __forceinline__ void lds_store_state(unsigned char *smem, uint32_t addr, uint32_t, const RowStateRegs<float> &s)
 {
     *reinterpret_cast<uint4 *>(smem + addr) =
         make_uint4(__float_as_uint(s.min1), __float_as_uint(s.min2), s.signs, s.idx);
 }
-__device__ __forceinline__ void lds_store_state(unsigned char *smem, uint32_t addr, const RowStateRegs<double> &s)
+__device__ __forceinline__ void lds_store_state(unsigned char *smem, uint32_t addr, uint32_t plane, const RowStateRegs<double> &s)
 {
     *reinterpret_cast<uint2 *>(smem + addr) = make_uint2(s.signs, s.idx);
-    *reinterpret_cast<double *>(smem + addr + 8) = s.min1;
-    *reinterpret_cast<double *>(smem + addr + 16) = s.min2;
+    *reinterpret_cast<double *>(smem + addr + plane) = s.min1;
+    *reinterpret_cast<double *>(smem + addr + 2 * plane) = s.min2;
 }
 __device__ __forceinline__ void lds_load_state_abs(uint32_t abs_addr, StateRaw<float> &r)
 {
@@ -83,10 +86,10 @@ __device__ __forceinline__ void lds_load_state_abs(uint32_t abs_addr, StateRaw<d
     r.mt = make_uint2(mt.x, mt.y);
 }
 // second step: the magnitude the row sent along the edge with slot number `slot` (min2 to its argmin edge)
-__device__ __forceinline__ void lds_load_magnitude(uint32_t, StateRaw<float> &, uint32_t) {}
-__device__ __forceinline__ void lds_load_magnitude(uint32_t abs_addr, StateRaw<double> &r, uint32_t slot)
+__device__ __forceinline__ void lds_load_magnitude(uint32_t, uint32_t, StateRaw<float> &, uint32_t) {}
+__device__ __forceinline__ void lds_load_magnitude(uint32_t abs_addr, uint32_t plane, StateRaw<double> &r, uint32_t slot)
 {
-    r.mag = lds_load<double>(abs_addr + (r.mt.y == slot ? 16u : 8u));
+    r.mag = lds_load<double>(abs_addr + (r.mt.y == slot ? 2 * plane : plane));
 }
 // message of a row along the edge with slot number `slot` whose sign sits `rank` bits below the top.
 // Magnitudes are never negative, so OR-ing the sign bit in is the multiplication by +-1.
@@ -164,7 +167,7 @@ qc_regular_kernel(const RegTables tb, const DecodeArgs a)
     // chunk of the check pass / columns per batch of the variable pass: halved for double, whose
     // values take two registers each (measured, float64: two columns per batch +3.4 % on the 2-row
     // NearEarth shape in spite of 100 bytes of spills, -12 % on the 4-row 802.11n shape)
-    enum { NB = CPT * MB, NS = NB * W, SB = RegState<T>::BYTES, NC = CPT * MB * W,
+    enum { NB = CPT * MB, NS = NB * W, SB = RegState<T>::BYTES, SS = RegState<T>::STRIDE, NC = CPT * MB * W,
            CH = sizeof(T) == 8 ? 8 : 16, VQ = sizeof(T) == 8 ? (MB == 2 ? 2 : 1) : 2 };
     static_assert(NS <= 32, "sign bits of a row must fit one register");
     static_assert(NS % 2 == 0 && NC % 2 == 0, "addresses are packed in pairs");
@@ -173,6 +176,7 @@ qc_regular_kernel(const RegTables tb, const DecodeArgs a)
     const int slots = FPW * MB * Zp;
     const uint32_t state_off = 0;
     const uint32_t post_off = (uint32_t)slots * SB;
+    const uint32_t plane = REG_F64_PLANES ? (uint32_t)slots * SS : 8u;      // float64: bytes from one part of a row state to the next
     const uint32_t flag_off = post_off + (uint32_t)((((size_t)FPW * n * sizeof(T)) + 15) & ~(size_t)15);
     const uint32_t post_rel = sizeof(T) == 8 ? post_off : 0u;   // added when a packed posterior address is used
     const uint32_t lds0 = lds_address(smem);                    // LDS address of the workgroup's dynamic shared memory
@@ -191,7 +195,7 @@ qc_regular_kernel(const RegTables tb, const DecodeArgs a)
     const int fbase = f * n;
     const int nbytes = (n + 7) >> 3;
     const T INF = t_inf(T(0));
-    const uint32_t my_state = state_off + (uint32_t)(grp * Zp + ic) * SB;
+    const uint32_t my_state = state_off + (uint32_t)(grp * Zp + ic) * SS;
 
     // ---- per-launch set-up: every LDS address this thread will ever use
     uint32_t rmask = 0;                 // present blocks of my block-row
@@ -228,7 +232,7 @@ qc_regular_kernel(const RegTables tb, const DecodeArgs a)
             const int s = tb.shifts[(b * NB + j) * W + k];
             int r = ic - s;
             r = r < 0 ? r + Z : r;
-            two[h] = state_off + (uint32_t)((f * MB + b) * Zp + r) * SB;
+            two[h] = state_off + (uint32_t)((f * MB + b) * Zp + r) * SS;
             if (W == 2 && k == 0) {
                 const int s1 = tb.shifts[(b * NB + j) * W + (W - 1)];
                 if (ic >= s && ic < s1) lo_first |= 1u << (q * MB + b);
@@ -392,7 +396,7 @@ qc_regular_kernel(const RegTables tb, const DecodeArgs a)
                 nw.min1 = ms_correct(nw.min1, a.ms_alpha, a.ms_beta);
                 nw.min2 = ms_correct(nw.min2, a.ms_alpha, a.ms_beta);
                 set_wave_prio(0);
-                lds_store_state(smem, my_state, nw);
+                lds_store_state(smem, my_state, plane, nw);
                 if (FPW == 1) {             // count of failing rows (bit 20: raised by the syndrome-only pass)
                     if (synd != 0ull && (tid & 63) == 0) atomicAdd(&flags[par], (int)__popcll(synd));
                 } else if (synd != 0ull) {
@@ -450,7 +454,7 @@ qc_regular_kernel(const RegTables tb, const DecodeArgs a)
                                 for (int k = 0; k < W; ++k) {
                                     const int q = q0 + dq, j = g + q * MB;
                                     if (q < CPT && (!HOLES || ((cmask[b] >> j) & 1u)))
-                                        lds_load_magnitude(sad[dq][b][k], st[dq][b][k], (uint32_t)(j * W + k));
+                                        lds_load_magnitude(sad[dq][b][k], plane, st[dq][b][k], (uint32_t)(j * W + k));
                                 }
                     }
 #pragma unroll

@@ -726,6 +726,15 @@ def test_heavy_circulants_on_the_message_plane_kernel(oracle_mod, monkeypatch):
                     assert np.array_equal(r['iters'], iters), (qc.row_degrees(), sm, budget, r['iters'], iters)
                     assert np.array_equal(r['converged'], conv) and np.array_equal(r['hard'], hard)
                     assert np.array_equal(r['soft'], soft)
+            # sum-product on the same kernel family (parity unpinned by the reference: against this build's CPU statement,
+            # on the frames that converge there)
+            assert eng.launch_info(prec=32, algo=ldpc_amd.ALGO_SUMPRODUCT)['lds_bytes'] == 163824
+            scale = np.float32(4 * 10 ** 0.34)
+            hs, is_, cs, _ = orc.spa(Y, float(scale), 50, prec=32, sign_mode=1, want_soft=False, threads=8)
+            r = eng.decode(Y * scale, 50, prec=32, algo=ldpc_amd.ALGO_SUMPRODUCT, sign_mode=1)
+            cv = cs == 1
+            assert cv.sum() >= 20, (qc.row_degrees(), int(cv.sum()))
+            assert np.array_equal(r['iters'][cv], is_[cv]) and np.array_equal(r['hard'][cv], hs[cv]) and r['converged'][cv].all()
             fast = eng.decode(Y, 50, prec=32, sign_mode=1, want_soft=True)
             monkeypatch.setenv('LDPC_HIP_NO_PLANES', '1')
             assert eng.launch_info(prec=32)['lds_bytes'] != 163824

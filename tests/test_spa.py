@@ -77,7 +77,7 @@ def test_oracle_spa_decodes_better_than_minsum(oracle_mod):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('name,snrs', [('nearEarth', (3.0, 3.5)), ('wifi_5_6', (4.0, 6.0)), ('rand_24_48', (2.0,)),
-                                       ('nearEarth_mut_w3', (3.4,))])
+                                       ('nearEarth_mut_w3', (3.4,)), ('nearEarth_mut_w7', (3.6,))])
 @pytest.mark.parametrize('prec', [64, 32])
 def test_gpu_spa_against_cpu_statement(oracle_mod, name, snrs, prec):
     """Same arithmetic type on both sides; the two differ only in the last bits of

@@ -9,6 +9,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def main():
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--algo', choices=('minsum', 'spa'), default='minsum')
+    args = ap.parse_args()
     import torch
     import ldpc_amd
     from ldpc_amd import codes
@@ -33,7 +37,9 @@ def main():
             for rep in range(3):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(stream)
-                eng.decode_device(llr, F, 50, prec=32, sign_mode=1, d_iters=iters, d_ones=ones)
+                eng.decode_device(llr, F, 50, prec=32, sign_mode=1, d_iters=iters, d_ones=ones,
+                                  algo=ldpc_amd.ALGO_SUMPRODUCT if args.algo == 'spa' else ldpc_amd.ALGO_MINSUM,
+                                  llr_scale=4.0 * 10 ** 0.35 if args.algo == 'spa' else 1.0)
                 e1.record(stream)
                 torch.cuda.synchronize()
                 ts.append(e0.elapsed_time(e1))
@@ -41,7 +47,7 @@ def main():
             mi = float(iters.float().mean())
             out.append(dict(case=name, frames=F, kernel_ms=t, info_gbps=7154 * F / (t * 1e-3) / 1e9, mean_iters=mi,
                             us_per_frame_iteration_per_cu=t * 1e3 * 256 / F / mi, fer=float((ones != 0).float().mean()),
-                            launch=eng.launch_info(prec=32)))
+                            launch=eng.launch_info(prec=32, algo=ldpc_amd.ALGO_SUMPRODUCT if args.algo == 'spa' else ldpc_amd.ALGO_MINSUM)))
             print(f"{name:60s} {out[-1]['info_gbps']:7.2f} Gbit/s  {mi:5.2f} iters  {out[-1]['us_per_frame_iteration_per_cu']:.2f} us/iteration/CU",
                   file=sys.stderr, flush=True)
             del llr
