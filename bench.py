@@ -27,6 +27,34 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (spec)
 BYTES_PER_FRAME = N_CODE * 4 + (N_CODE + 7) // 8 + 4 + 1 + 4
 
 
+SPA_ENGINE = [None]      # the engine whose sum-product kernel the CPU leg checks (set by main)
+
+
+def spa_agreement(om, orc, n_threads, frames=20000):
+    """Sum-product has no counterpart in the reference, so its only oracle is this build's CPU statement: the
+    fraction of frames on which the GPU kernel and that statement agree in (iterations, status, bits), float32,
+    NearEarth at two SNR points, 2*10^4 device-made frames each.  Part of the CPU leg: the oracle is the checker."""
+    import numpy as np
+    import torch
+    import ldpc_amd
+    eng = SPA_ENGINE[0]
+    out = []
+    llr = torch.empty((frames, eng.n), dtype=torch.float32, device='cuda')
+    for snr in (3.1, 3.3):
+        eng.channel_awgn_device(llr, frames, snr, seed=777001)
+        eng.sync()
+        Y = llr.cpu().numpy()
+        scale = 4 * 10 ** (snr / 10)
+        hard, iters, conv, _ = orc.spa(Y, scale, 50, prec=32, want_soft=False, threads=n_threads)
+        r = eng.decode(Y * np.float32(scale), 50, prec=32, algo=ldpc_amd.ALGO_SUMPRODUCT)
+        ok = (r['iters'] == iters) & (r['converged'] == conv) & (r['hard'] == hard).all(axis=1)
+        cv = conv == 1
+        out.append({'code': 'NearEarth', 'snr_db': snr, 'frames': frames, 'identical_fraction': float(ok.mean()),
+                    'identical_fraction_among_cpu_converged': float(ok[cv].mean()) if cv.any() else None,
+                    'cpu_converged_fraction': float(cv.mean()), 'bar': 0.9999, 'meets_bar': bool(ok.mean() >= 0.9999)})
+    return out
+
+
 def cpu_baseline(llr_dev, n_frames, n_threads, slice_frames=16384):
     """The CPU oracle (C restatement of ldpc.py's decoder, float64) timed on the host cores:
     the first n_frames frames of the batch, fetched and decoded slice by slice (only the
@@ -52,7 +80,8 @@ def cpu_baseline(llr_dev, n_frames, n_threads, slice_frames=16384):
         it_all.append(iters)
         done += m
     iters = np.concatenate(it_all)
-    return dict(value=K_INFO * n_frames / tn / 1e9, unit='Gbit/s', cores=n_threads, kind='port',
+    spa = spa_agreement(om, orc, n_threads) if SPA_ENGINE[0] is not None else None
+    return dict(spa_agreement=spa, value=K_INFO * n_frames / tn / 1e9, unit='Gbit/s', cores=n_threads, kind='port',
                 sample=f'first {n_frames} frames of the same batch (3.5 dB, <=50 iterations, float64), '
                        f'{n_threads} OpenMP threads over frames, {tn:.2f} s of decode calls',
                 single_core_value=K_INFO * one / t1 / 1e9, single_core_frames=one,
@@ -245,6 +274,9 @@ def secondary(eng, llr, F, args, hard, iters, conv, ones, stream, dev):
         with ldpc_amd.Decoder(code, device=eng.device) as e2:
             e2.set_stream(stream.cuda_stream)
             timed(name + ', corrected sign rule, %.1f dB' % args.snr, e2, llr, Fm, K_INFO, prec=32, sign_mode=ldpc_amd.SIGN_CORRECTED)
+            if 'weight 3' in name:
+                timed(name.replace('min-sum', 'sum-product') + ', corrected sign rule, %.1f dB' % args.snr, e2, llr, Fm, K_INFO, prec=32,
+                      sign_mode=ldpc_amd.SIGN_CORRECTED, algo=ldpc_amd.ALGO_SUMPRODUCT, llr_scale=4.0 * 10 ** (args.snr / 10))
     # the state of a gym episode after 40 actions (the environment keeps every action's circulant): beyond the
     # message-plane kernels' limits, on the table-driven kernel; a poor code, so most frames run all iterations
     late = codes.gym_episode_state(base, 40, seed=20211227)
@@ -503,6 +535,8 @@ def main():
         if not args.no_cpu and world == 1 and not spa:
             ncpu = min(16, os.cpu_count() or 1)
             m = min(args.cpu_frames, F)
+            SPA_ENGINE[0] = eng
+            eng.set_stream(None)
             base, it_cpu = cpu_baseline(llr, m, ncpu)
             base.update(cpu_model=cpu_model(), os_cpu_count=os.cpu_count(),
                         cores_note='OpenMP threads used = min(16, os.cpu_count()): the GPU box gives one job 16 host threads')

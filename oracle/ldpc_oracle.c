@@ -90,7 +90,22 @@ static int f32_syndrome_is_zero(const oracle_graph *g, const float *x) { SYNDROM
 
 #define REAL float
 #define FABS fabsf
-#define PHI(x) log1pf(2.0f / expm1f(x))
+/* Experiment switch (oracle_set_spa_phi_form): 1 = phi restated the way the float32 message-plane kernel
+ * computes it (qc_planes.h planes_phi: three branches on exp2 / log2 / reciprocal with fused polynomial steps),
+ * on the host's exp2f / log2f.  Tells whether the GPU's disagreement with this statement on frames that never
+ * converge comes from the form of phi or from the last bits of the hardware's transcendental units. */
+static int oracle_spa_phi_form = 0;
+static float phi_device_form(float x)
+{
+    const float t = exp2f(x * -1.4426950408889634f);
+    const float t2 = t * t;
+    const float series = (t + t) * fmaf(t2, fmaf(t2, fmaf(t2, 0.14285715f, 0.2f), 0.33333334f), 1.0f);
+    const float om_small = x * fmaf(-x, fmaf(-x, fmaf(-x, fmaf(-x, 0.008333334f, 0.041666668f), 0.16666667f), 0.5f), 1.0f);
+    const float om = x < 0.0625f ? om_small : 1.0f - t;
+    const float lg = log2f((1.0f + t) * (1.0f / om)) * 0.6931471805599453f;
+    return x >= 2.0f ? series : lg;
+}
+#define PHI(x) (oracle_spa_phi_form ? phi_device_form(x) : log1pf(2.0f / expm1f(x)))
 #define FN(name) CAT(f32_, name)
 #include "minsum_impl.h"
 #include "spa_impl.h"
@@ -103,6 +118,7 @@ static int f32_syndrome_is_zero(const oracle_graph *g, const float *x) { SYNDROM
  * purpose: the HIP library takes the two parameters as float. */
 static float oracle_ms_alpha = 1.0f, oracle_ms_beta = 0.0f;
 void oracle_set_minsum_scaling(float alpha, float beta) { oracle_ms_alpha = alpha; oracle_ms_beta = beta; }
+void oracle_set_spa_phi_form(int form) { oracle_spa_phi_form = form; }
 
 /* Batch drivers.  y: [frames][n]; hard: [frames][n] bytes 0/1 or NULL;
  * iters: [frames]; conv: [frames]; soft: [frames][n] or NULL.

@@ -129,8 +129,10 @@ class Oracle:
         finally:
             lib().oracle_set_minsum_scaling(1.0, 0.0)
 
-    def spa(self, y, llr_scale, max_iters=50, prec=64, sign_mode=0, want_soft=True, threads=1):
-        """Sum-product (tanh rule) on LLR = llr_scale * y.  No counterpart in the reference."""
+    def spa(self, y, llr_scale, max_iters=50, prec=64, sign_mode=0, want_soft=True, threads=1, phi_form=0):
+        """Sum-product (tanh rule) on LLR = llr_scale * y.  No counterpart in the reference.
+        phi_form=1 (float32 only, an experiment): phi in the three-branch form of the GPU kernel."""
+        lib().oracle_set_spa_phi_form(int(phi_form))
         if prec == 64:
             return self._run('oracle_spa_f64', np.float64, y, max_iters, sign_mode, want_soft, threads,
                              extra=(ctypes.c_double(llr_scale),))

