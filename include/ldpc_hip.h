@@ -98,6 +98,12 @@ int ldpc_create_csr(int device, int m, int n, const int32_t *row_ptr,
 
 void ldpc_destroy(ldpc_handle *h);
 
+/* A destroyed handle leaves its stream, its table allocation and its small buffers (at most 8 sets per device)
+ * for the next handle on the same device: the gym builds a new decoder at every step (ldpc_env.py:313, 370).
+ * A long-running host that is done decoding gives them back with this call; returns the number of sets freed.
+ * No counterpart in the reference (numba keeps its device arrays until the process ends, ldpcCUDA.py:538-564). */
+int ldpc_release_pool(void);
+
 /* Code dimensions of a handle. */
 int ldpc_get_dims(const ldpc_handle *h, int *m, int *n, int *edges);
 

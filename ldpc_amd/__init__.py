@@ -9,7 +9,7 @@ library or without a HIP device raises.
 """
 from . import codes, common  # noqa: F401
 from .engine import (ALGO_MINSUM, ALGO_SUMPRODUCT, COUNTER_FIELDS, SIGN_CORRECTED, SIGN_REFERENCE,  # noqa: F401
-                     Comm, Decoder, LdpcHipError, comm_unique_id, device_count, library_path)
+                     Comm, Decoder, LdpcHipError, comm_unique_id, device_count, library_path, release_pool)
 
-__all__ = ['codes', 'common', 'Comm', 'comm_unique_id', 'Decoder', 'LdpcHipError', 'device_count', 'library_path', 'ALGO_MINSUM',
+__all__ = ['codes', 'common', 'Comm', 'comm_unique_id', 'Decoder', 'LdpcHipError', 'device_count', 'library_path', 'release_pool', 'ALGO_MINSUM',
            'ALGO_SUMPRODUCT', 'SIGN_REFERENCE', 'SIGN_CORRECTED', 'COUNTER_FIELDS']

@@ -7,7 +7,7 @@ LIB_NAME = 'libldpc_hip.so'
 
 # every symbol include/ldpc_hip.h declares
 SYMBOLS = (
-    'ldpc_last_error', 'ldpc_device_count', 'ldpc_create_qc', 'ldpc_create_csr', 'ldpc_destroy',
+    'ldpc_last_error', 'ldpc_device_count', 'ldpc_create_qc', 'ldpc_create_csr', 'ldpc_destroy', 'ldpc_release_pool',
     'ldpc_get_dims', 'ldpc_set_minsum_scaling', 'ldpc_set_pass_counters', 'ldpc_set_stream', 'ldpc_sync', 'ldpc_decode', 'ldpc_decode_chained',
     'ldpc_reset_state', 'ldpc_decode_device', 'ldpc_decode_device_noalloc',
     'ldpc_channel_awgn_device', 'ldpc_eval_awgn', 'ldpc_get_launch_info',
@@ -72,6 +72,8 @@ def load():
     L.ldpc_create_csr.argtypes = [i32, i32, i32, vp, vp, c.POINTER(vp)]
     L.ldpc_destroy.restype = None
     L.ldpc_destroy.argtypes = [vp]
+    L.ldpc_release_pool.restype = i32
+    L.ldpc_release_pool.argtypes = []
     L.ldpc_get_dims.restype = i32
     L.ldpc_get_dims.argtypes = [vp, c.POINTER(i32), c.POINTER(i32), c.POINTER(i32)]
     L.ldpc_set_minsum_scaling.restype = i32

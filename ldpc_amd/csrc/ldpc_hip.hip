@@ -1334,6 +1334,28 @@ extern "C" int ldpc_device_count(void)
     return cnt;
 }
 
+extern "C" int ldpc_release_pool(void)
+{
+    // what destroyed handles left behind for their successors: streams, table allocations, small buffers
+    std::vector<PooledParts> all;
+    std::vector<int> dev;
+    {
+        std::lock_guard<std::mutex> g(g_pool_mutex);
+        for (int d = 0; d < 64; ++d) {
+            for (PooledParts &p : g_pool[d]) { all.push_back(p); dev.push_back(d); }
+            g_pool[d].clear();
+        }
+    }
+    for (size_t k = 0; k < all.size(); ++k) {
+        if (hipSetDevice(dev[k]) != hipSuccess) continue;
+        PooledParts &p = all[k];
+        if (p.stream) { (void)hipStreamSynchronize(p.stream); (void)hipStreamDestroy(p.stream); }
+        if (p.arena) (void)hipFree(p.arena);
+        for (DevBuf &b : p.bufs) b.release();
+    }
+    return (int)all.size();
+}
+
 extern "C" void ldpc_destroy(ldpc_handle *h)
 {
     if (!h) return;
@@ -1513,7 +1535,7 @@ extern "C" int ldpc_create_qc(int device, int Z, int mb, int nb, const int32_t *
     ldpc_handle *h = new (std::nothrow) ldpc_handle();
     if (!h) return fail(LDPC_E_NOMEM, "out of host memory");
     int rc = open_device(device, h);
-    if (rc) { delete h; return rc; }
+    if (rc) { ldpc_destroy(h); return rc; }      // (returns what open_device took from the pool)
     h->is_qc = !wide;
     h->wide = max_deg > 64;
     h->m = mb * Z; h->n = nb * Z; h->E = blk_ptr[nblk] * Z; h->max_row_deg = max_deg;
@@ -1736,7 +1758,7 @@ extern "C" int ldpc_create_csr(int device, int m, int n, const int32_t *row_ptr,
     ldpc_handle *h = new (std::nothrow) ldpc_handle();
     if (!h) return fail(LDPC_E_NOMEM, "out of host memory");
     int rc = open_device(device, h);
-    if (rc) { delete h; return rc; }
+    if (rc) { ldpc_destroy(h); return rc; }      // (returns what open_device took from the pool)
     h->is_qc = false;
     h->wide = max_deg > 64;
     h->m = m; h->n = n; h->E = E; h->max_row_deg = max_deg;
@@ -2022,8 +2044,10 @@ static bool packed_applies(const ldpc_handle *h, int prec, bool chained)
 static int blocks_per_cu(int device, const void *fn, int block, size_t lds, int *out, bool needs_lds_at_zero = false)
 {
     struct Key { int device; const void *fn; int block; size_t lds; int per_cu; };
+    struct Attr { int device; const void *fn; size_t lds; };      // largest dynamic LDS size a kernel was set up for
     static std::mutex mu;
     static std::vector<Key> seen;
+    static std::vector<Attr> attrs;
     std::lock_guard<std::mutex> g(mu);
     for (const Key &k : seen)
         if (k.device == device && k.fn == fn && k.block == block && k.lds == lds) { *out = k.per_cu; return 0; }
@@ -2034,7 +2058,18 @@ static int blocks_per_cu(int device, const void *fn, int block, size_t lds, int 
         if (at.sharedSizeBytes != 0)
             return fail(LDPC_E_DEVICE, "kernel built with %zu bytes of static LDS; its dynamic LDS would not start at 0", (size_t)at.sharedSizeBytes);
     }
-    if (lds > 0) HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // The attribute belongs to the kernel, not to one launch geometry: codes that share a template instance
+    // with different LDS sizes must leave it at the largest of them, so it is only ever raised.
+    if (lds > 0) {
+        Attr *at = nullptr;
+        for (Attr &a : attrs)
+            if (a.device == device && a.fn == fn) at = &a;
+        if (!at || at->lds < lds) {
+            HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            if (at) at->lds = lds;
+            else attrs.push_back(Attr{device, fn, lds});
+        }
+    }
     int per_cu = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, block, lds));
     if (per_cu < 1) per_cu = 1;

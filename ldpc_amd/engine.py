@@ -24,6 +24,12 @@ def library_path():
     return _lib.library_path()
 
 
+def release_pool():
+    """Free what closed decoders left for their successors (streams, table allocations, small buffers);
+    returns the number of sets freed.  For a long-running process that is done decoding."""
+    return int(_lib.load().ldpc_release_pool())
+
+
 def device_count():
     return int(_lib.load().ldpc_device_count())
 

@@ -757,3 +757,21 @@ def test_heavy_circulants_on_the_message_plane_kernel(oracle_mod, monkeypatch):
             hard, iters, conv, soft = orc.minsum(Y, 50, prec=32, sign_mode=1, threads=8)
             r = eng.decode(Y, 50, prec=32, sign_mode=1, want_soft=True)
             assert np.array_equal(r['iters'], iters) and np.array_equal(r['soft'], soft)
+
+
+def test_release_pool_gives_back_what_closed_handles_left(oracle_mod):
+    """A closed handle leaves its stream and allocations for the next one (the gym makes a decoder per step,
+    ldpc_env.py:313, 370); ldpc_release_pool frees them, and decoding goes on as before afterwards."""
+    import ldpc_amd
+    qc, H = build_code('nearEarth_mut_w3')
+    Y = make_llrs(12, 3.5, qc.n, 4)
+    ref = oracle_mod.Oracle(H).minsum(Y, 50, prec=32, threads=4)
+    for _ in range(3):
+        with ldpc_amd.Decoder(qc) as eng:
+            r = eng.decode(Y, 50, prec=32, want_soft=True)
+            assert np.array_equal(r['iters'], ref[1]) and np.array_equal(r['soft'], ref[3])
+    assert ldpc_amd.release_pool() >= 1
+    assert ldpc_amd.release_pool() == 0
+    with ldpc_amd.Decoder(qc) as eng:
+        r = eng.decode(Y, 50, prec=32, want_soft=True)
+        assert np.array_equal(r['iters'], ref[1]) and np.array_equal(r['soft'], ref[3])
