@@ -55,26 +55,40 @@ class berStatistics:
         if codewordSize is None:
             codewordSize = self.codewordSize
         rows = self.stats
-        k = len(rows)
-        scatterSNR = np.zeros(k, DECIMAL)
-        scatterBER = np.zeros(k, DECIMAL)
-        scatterITR = np.zeros(k, DECIMAL)
         snrAxis = np.array(sorted(self.snrAxis))
         p = len(snrAxis)
-        snrSum = np.zeros(p, DECIMAL)
-        errSum = np.zeros(p, DECIMAL)
-        itrSum = np.zeros(p, DECIMAL)
-        count = np.zeros(p, DECIMAL)
-        for t, row in enumerate(rows):
-            scatterSNR[t] = row[1]
-            scatterBER[t] = row[5] / codewordSize
-            scatterITR[t] = row[6]
-            at = np.where(snrAxis == row[0])
-            snrSum[at] = snrSum[at] + row[1]
-            errSum[at] = errSum[at] + row[5]
+        # The scatter columns are the rows' columns rounded to float32.  The per-point sums are what the reference's
+        # loop leaves in its float32 arrays (common.py:210-222): row after row, sum[at] = sum[at] + value, where
+        # the actual SNR is a float64 scalar (added in float64, the sum rounded to float32 when it is stored) and
+        # the error count an integer (added in float32).  Same arithmetic here on scalars, without a search of the
+        # SNR axis per row (that search was most of a gym step's host time).
+        scatterSNR = np.array([r[1] for r in rows], np.float64).astype(DECIMAL)
+        scatterBER = (np.array([r[5] for r in rows], np.float64) / codewordSize).astype(DECIMAL)
+        scatterITR = np.array([r[6] for r in rows], np.float64).astype(DECIMAL)
+        where = {v: t for t, v in enumerate(snrAxis.tolist())}
+        f32 = np.float32
+        snr_acc = [0.0] * p                      # float32 values held as Python floats
+        err_acc = [f32(0)] * p
+        itr_acc = [f32(0)] * p
+        cnt_acc = [f32(0)] * p
+        one = f32(1)
+        for row in rows:
+            at = where.get(float(row[0]))
+            if at is None:                       # (a point that is not on the axis counts nowhere, as in the reference)
+                continue
+            v = row[1]
+            if isinstance(v, (np.floating, float)) and not isinstance(v, np.float32):
+                snr_acc[at] = float(f32(snr_acc[at] + float(v)))
+            else:
+                snr_acc[at] = float(f32(snr_acc[at]) + f32(v))
+            err_acc[at] = err_acc[at] + f32(row[5])
             if fixAverageIterations:
-                itrSum[at] = itrSum[at] + row[6]
-            count[at] = count[at] + 1
+                itr_acc[at] = itr_acc[at] + f32(row[6])
+            cnt_acc[at] = cnt_acc[at] + one
+        snrSum = np.array(snr_acc, np.float64).astype(DECIMAL)
+        errSum = np.array(err_acc, DECIMAL)
+        itrSum = np.array(itr_acc, DECIMAL)
+        count = np.array(cnt_acc, DECIMAL)
         with np.errstate(divide='ignore', invalid='ignore'):
             return (scatterSNR, scatterBER, scatterITR, snrAxis, snrSum / count,
                     errSum / (count * codewordSize), itrSum / count)

@@ -379,3 +379,48 @@ def test_LdpcEnv_state_transitions_follow_the_reference_step():
         dense[xr * Z:(xr + 1) * Z, yr * Z:(yr + 1) * Z] = xy
         env.step(a)
         assert np.array_equal(env.state, dense)
+
+
+def test_getStatsV2_equals_the_reference_loop():
+    """berStatistics.getStatsV2 computes its per-point sums on scalars; the statement it must equal is the
+    reference's loop over rows into float32 arrays (common.py:195-227), kept here: every returned array
+    identical -- values and dtypes -- on random row sets with float32 and float64 SNR keys, error counts
+    beyond 2^24 and with the iteration sums switched on."""
+    from ldpc_amd import common
+    DEC = np.float32
+
+    def loop_form(self, codewordSize, fix):
+        rows = self.stats
+        k = len(rows)
+        scatterSNR, scatterBER, scatterITR = np.zeros(k, DEC), np.zeros(k, DEC), np.zeros(k, DEC)
+        snrAxis = np.array(sorted(self.snrAxis))
+        p = len(snrAxis)
+        snrSum, errSum, itrSum, count = np.zeros(p, DEC), np.zeros(p, DEC), np.zeros(p, DEC), np.zeros(p, DEC)
+        for t, row in enumerate(rows):
+            scatterSNR[t] = row[1]
+            scatterBER[t] = row[5] / codewordSize
+            scatterITR[t] = row[6]
+            at = np.where(snrAxis == row[0])
+            snrSum[at] = snrSum[at] + row[1]
+            errSum[at] = errSum[at] + row[5]
+            if fix:
+                itrSum[at] = itrSum[at] + row[6]
+            count[at] = count[at] + 1
+        with np.errstate(divide='ignore', invalid='ignore'):
+            return (scatterSNR, scatterBER, scatterITR, snrAxis, snrSum / count, errSum / (count * codewordSize), itrSum / count)
+
+    prng = np.random.RandomState(3)
+    for trial in range(60):
+        b = common.berStatistics(8176)
+        pts = [np.float32(3.0), np.float32(3.2), np.float32(3.4)] if trial % 2 else [3.0, 3.2, 3.4, 3.6]
+        for _ in range(int(prng.randint(1, 200))):
+            s = pts[prng.randint(len(pts))]
+            sig = float(np.sqrt(0.5 / 10 ** (float(s) / 10)))
+            dec = int(prng.randint(0, 3000000)) if trial % 3 == 0 else int(prng.randint(0, 300))
+            b.addEntry(s, sig, sig * (1 + 0.05 * prng.randn()), int(prng.randint(0, 900)), dec, int(prng.randint(0, 51)), 50, 'test')
+        for fix in (False, True):
+            want, got = loop_form(b, 8176, fix), b.getStatsV2(8176, fix)
+            for x, y in zip(want, got):
+                assert x.dtype == y.dtype and np.array_equal(x, y, equal_nan=True), (trial, fix)
+    empty = common.berStatistics(8176).getStatsV2()
+    assert all(len(x) == 0 for x in empty)

@@ -10,6 +10,14 @@ def test_roundtripCompression():
     assert status == 'OK'
 
 
+# With the reference's seed (460101) and its 60 frames per point, three frames do not decode at 3.4 dB and none at
+# 3.6 dB -- in this build's float32 oracle and on the GPU alike: (frame index inside the point, bit errors left).
+# PARITY UNPINNED for this outcome: no fixture of the reference covers its GPU path (dense float32 sums, stop test
+# every 6th iteration over half the rows, ldpcCUDA.py:465-482, 637-639), so whether ITS run of these 60 frames ends
+# 'OK' is not known here; recorded so that a change in what this build decodes shows.
+FAILING_FRAMES_SEED_460101 = {3.4: [(38, 104), (43, 144), (56, 133)], 3.6: []}
+
+
 @pytest.mark.gpu
 def test_ldpcCUDAdecoder(oracle_mod):
     """test_ldpc.py:25-28.  The reference asserts status == 'OK', i.e. no bit error in 60 frames at 3.4 and at
@@ -39,6 +47,10 @@ def test_ldpcCUDAdecoder(oracle_mod):
                 checked += 1
             k += 1
     assert checked == sum(1 for r in rows if r[0] >= 3.4 and r[5] > 0)
+    for p, snr in enumerate((3.0, 3.2, 3.4, 3.6)):
+        if snr in FAILING_FRAMES_SEED_460101:
+            got = [(k, int(rows[p * 60 + k][5])) for k in range(60) if rows[p * 60 + k][5] > 0]
+            assert got == FAILING_FRAMES_SEED_460101[snr], (snr, got)
     _, status = ldpcCUDA.testNearEarth(8, graphics=False)
     assert status == 'OK'
 
