@@ -72,11 +72,11 @@ def _evaluate_on(eng, seed, SNRpoints, numberOfIterations, numOfTransmissions, p
     if deviceRng:
         cnt, pf = eng.eval_awgn(list(SNRpoints), numOfTransmissions, int(seed), max_iters=budget,
                                 prec=prec, per_frame=True)
+        frames = pf.tolist()                    # Python floats at once (indexing the array element by element is slower)
         for s in range(len(SNRpoints)):
             sigma = np.sqrt(0.5 / (10 ** (SNRpoints[s] / 10)))
-            for t in range(numOfTransmissions):
-                sa, unc, dec, it = pf[s, t]
-                berStats.addEntry(SNRpoints[s], sigma, float(sa), int(unc), int(dec), int(it),
+            for sa, unc, dec, it in frames[s]:
+                berStats.addEntry(SNRpoints[s], sigma, sa, int(unc), int(dec), int(it),
                                   numberOfIterations, 'test')
         return berStats
     localPrng = np.random.RandomState(seed)
@@ -114,6 +114,13 @@ def evaluateCodeCudaWrapper(seeds, SNRpoints, numberOfIterations, parityMatrix, 
     berStats = common.berStatistics()
     newNumOfTransmissions = numOfTransmissions // numberOfCudaDevices
     parityMatrix, _ = _ldpc._code_key(parityMatrix)       # the structure of a dense matrix is read once, not per device
+    from .engine import device_count
+    if numberOfCudaDevices <= 1 or device_count() <= 1:
+        # one card serves every logical device in turn: starting a thread per call costs a fifth of a gym step
+        for d in range(numberOfCudaDevices):
+            berStats = berStats.add(evaluateCodeCuda(seeds[d], SNRpoints, numberOfIterations, parityMatrix,
+                                                     newNumOfTransmissions, 'None', d, prec, deviceRng))
+        return berStats
     with concurrent.futures.ThreadPoolExecutor(max_workers=max(1, numberOfCudaDevices)) as pool:
         futs = [pool.submit(evaluateCodeCuda, seeds[d], SNRpoints, numberOfIterations, parityMatrix,
                             newNumOfTransmissions, 'None', d, prec, deviceRng)
