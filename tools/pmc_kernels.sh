@@ -15,7 +15,9 @@ run f64_regular        200000 33735 --prec 64 --snr 3.5 &&
 run f32_spa_planes     200000 33735 --algo spa --snr 3.5 &&
 run f32_heavy_w3       200000 33735 --code nearEarth_w3 --sign-mode 1 --snr 3.5 &&
 run f32_heavy_w7       200000 33735 --code nearEarth_w7 --sign-mode 1 --snr 3.5 &&
-run f32_table_driven   50000  33735 --code nearEarth_episode40 --sign-mode 1 --snr 3.5 &&
+run f32_heavyqc_ep40   20000  33735 --code nearEarth_episode40 --sign-mode 1 --snr 3.5 &&
+LDPC_HIP_TEST_HOOKS=1 LDPC_HIP_NO_HEAVYQC=1 run f32_table_driven_ep40 20000 33735 --code nearEarth_episode40 --sign-mode 1 --snr 3.5 &&
+run f32_spa_heavy_w3   200000 33735 --code nearEarth_w3 --algo spa --sign-mode 1 --snr 3.5 &&
 run f32_packed_wifi12  1000000 8028 --code wifi_1/2 --sign-mode 1 --snr 2.0 &&
 run f32_slots_wifi56   1000000 8028 --code wifi_5/6 --sign-mode 1 --snr 4.0 &&
 echo all done

@@ -23,7 +23,7 @@ tot = collections.defaultdict(float); n = collections.Counter()
 for f in glob.glob(out + '/pass*/**/*counter_collection.csv', recursive=True):
     for row in csv.DictReader(open(f)):
         k = row['Kernel_Name']
-        if 'minsum' in k or 'regular' in k or 'planes' in k:
+        if 'minsum' in k or 'regular' in k or 'planes' in k or 'heavy' in k or 'spa' in k:
             tot[row['Counter_Name']] += float(row['Counter_Value']); n[row['Counter_Name']] += 1
 for k in sorted(tot): print(f'{k:28s} {tot[k]:18.0f}  (dispatches {n[k]})')
 PY

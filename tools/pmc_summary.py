@@ -23,7 +23,7 @@ def main():
     for path in glob.glob(out_dir + "/pass*/**/*counter_collection.csv", recursive=True):
         for row in csv.DictReader(open(path)):
             name = row["Kernel_Name"]
-            if "planes" in name or "minsum" in name or "regular" in name:
+            if "planes" in name or "minsum" in name or "regular" in name or "heavy" in name or "spa" in name:
                 kernel = name
                 total[row["Counter_Name"]] += float(row["Counter_Value"])
                 launches[row["Counter_Name"]] += 1

@@ -29,7 +29,7 @@ def main():
     elif args.code == 'nearEarth_w7':
         code = codes.near_earth().with_block(1, 9, [3, 50, 121, 200, 317, 404, 499])
     elif args.code == 'nearEarth_episode40':
-        code = codes.gym_episode_state(codes.near_earth(), 40, 1)
+        code = codes.gym_episode_state(codes.near_earth(), 40, 20211227)       # the state bench.py's secondary line times
     else:
         code = codes.wifi_1944(args.code.split('_', 1)[1])
     eng = ldpc_amd.Decoder(code)
