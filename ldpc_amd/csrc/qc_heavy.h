@@ -26,12 +26,13 @@ enum {
 // makes the address.
 //   posteriors   [nb][2Z] float
 //   dummy        [Zp] float, +inf: what the padding edges of a row read (never a minimum, sign +)
-//   row records  [nwu][mb][2Z] x 16 bytes { 2*min1, 2*min2, arg-min edge, sign word w }: the messages a
-//                row sent last, one record per sign word so that a column fetches all it needs about
-//                one edge with one 16-byte read (nwu <= 2), or
-//   row records  [mb][2Z] x 16 bytes { 2*min1, 2*min2, arg-min edge, - } and sign words [nwu][mb][2Z] x 4
-//                (nwu 3 or 4: the replicated form would not fit)
+//   row records  [nwu][mb][2Z] x 16 bytes { 2*min1, 2*min2, column-table word of the arg-min edge, sign word w }:
+//                the messages a row sent last, one record per sign word so that a column fetches all it needs
+//                about one edge with one 16-byte read (nwu <= 2), or
+//   row records  [mb][2Z] x 16 bytes { 2*min1, 2*min2, column-table word of the arg-min edge, - } and sign words
+//                [nwu][mb][2Z] x 4 (nwu 3 or 4: the replicated form would not fit)
 //   flags        4 words
+//   row table    [2][mb][tabw] words (HeavyTables::rowtab)
 struct HeavyGeom {
     uint32_t Z, Z2, Zp, mb, nb, nwu;
     bool split;                 // sign words apart from the magnitudes

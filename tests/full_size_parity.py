@@ -7,8 +7,9 @@ the GPU box (about five minutes of 16 host threads; too long for the collected s
     python -u tests/full_size_parity.py --out gpurun_out/full_size_parity.json
     python -u tests/full_size_parity.py --codes nearEarth_mut_w3:3.5,wifi_1/2:2.0 --frames64 200000 --out ...
 
---codes: name:snr pairs; names are those of the golden set (tests/conftest.py build_code) and wifi_<rate> for the four
-802.11n n = 1944 tables.
+--codes: name:snr pairs; names are those of the golden set (tests/conftest.py build_code), wifi_<rate> for the four
+802.11n n = 1944 tables and episode<k> for NearEarth after k gym actions (ldpc_env.py:293-317; the states of
+tools/bench_episode.py, which the heavy-circulant kernel decodes).
 """
 import argparse
 import json
@@ -47,6 +48,9 @@ def main():
     for name, snr in todo:
         if name.startswith('wifi_') and '/' in name:
             qc = codes_mod.wifi_1944(name.split('_', 1)[1])
+            H = qc.to_dense()
+        elif name.startswith('episode'):
+            qc = codes_mod.gym_episode_state(codes_mod.near_earth(), int(name[len('episode'):]), seed=20211227)
             H = qc.to_dense()
         else:
             qc, H = build_code(name)
