@@ -8,7 +8,6 @@ export TMPDIR=/tmp
 R=${1:-r02}; COMMIT=${2:-unknown}
 O=gpurun_out/$R
 mkdir -p $O
-timeout -k 10 400 python3 bench.py > $O/bench.json 2> $O/bench.err || { echo bench failed; exit 1; }
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 bench.py --no-cpu --no-secondary > $O/bench_under_rocprof.json 2> $O/prof.err || { echo rocprof failed; exit 1; }
 bash tools/pmc_passes.sh $O/pmc --frames 1000000 --snr 3.5 --budget 50 > $O/pmc.txt 2>&1 || { echo pmc failed; tail -5 $O/pmc.txt; exit 1; }
 python3 tools/pmc_summary.py $O/pmc 1000000 33735 $O/f32_planes_pmc_summary.json "tools/pmc_passes.sh: python3 tools/prof_decode.py --frames 1000000 --snr 3.5 --budget 50 (library commit $COMMIT)" > /dev/null || { echo summary failed; exit 1; }
@@ -25,4 +24,8 @@ json.dump({'prec32_frames1000000': {'hbm_bytes_per_launch': s['hbm_bytes_per_lau
                                     'valu_busy_frac': s['valu_busy_frac'], 'lds_busy_frac': s['lds_busy_frac']}},
           open(o + '/hbm_traffic.json', 'w'), indent=1)
 PY
+# the bench line last, reading the counter passes just taken (traffic_source.stale: false)
+cp $O/hbm_traffic.json profiles/hbm_traffic.json
+cp $O/f32_planes_pmc_summary.json profiles/${R}_f32_planes_pmc_summary.json
+timeout -k 10 400 python3 bench.py > $O/bench.json 2> $O/bench.err || { echo bench failed; exit 1; }
 echo done
